@@ -1,0 +1,12 @@
+"""brickmap_amd -- MI355X-native voxel brickmap path tracer (hot path of stijnherfst/BrickMap).
+
+The package is a thin host-side mirror of the reference's Scene / Camera / State /
+launch_kernels interface over the C-ABI of libbrickmap_hip.so (include/brickmap.h); all
+rendering happens in hand-written HIP kernels for gfx950 (brickmap_amd/csrc/trace.hip).
+"""
+from ._lib import (BM_FLAG_COUNTERS, BM_FLAG_PRIMARY_ONLY, BRICK_INDEX_BITS, BRICK_LOADED_BIT, BRICK_LOD_BITS,  # noqa: F401
+                   BRICK_REQUESTED_BIT, BRICK_UNLOADED_BIT, BrickmapError, load)
+from .host import Camera, Scene, State, launch_kernels, local_rows, FrameParams  # noqa: F401
+from . import dist  # noqa: F401
+
+__all__ = ["Scene", "Camera", "State", "FrameParams", "launch_kernels", "local_rows", "dist", "load", "BrickmapError"]

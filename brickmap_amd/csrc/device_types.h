@@ -1,0 +1,61 @@
+// device_types.h -- kernel argument blocks shared by the host scene code and the HIP kernels.
+#pragma once
+#include <cstdint>
+
+namespace bm {
+
+// Device view of the scene (the reference passes Scene::GPUScene by value, Scene.h:9-17).
+//
+// HBM layout (DESIGN.md "Data layout"):
+//   index_grid  u32[supercells * 4096]   supercell-major; supercell id = sx + sy*sg_xy + sz*sg_xy^2,
+//                                         word (lx + 16*ly + 256*lz) inside it  -- the reference's
+//                                         addressing (voxel.cuh:197-198) minus its pointer table
+//   brick_base  u32[supercells]          first arena slot of each supercell (exclusive prefix sum of
+//                                         its non-empty brick count) -- replaces the Brick** table
+//   brick_arena 64 B * total_bricks      exact-fit pool; slot = brick_base[sc] + (word & 0xFFF)
+//   load_queue  int3[queue_cap] + count  brick-request ring (voxel.cuh:228-245)
+struct DeviceScene {
+	uint32_t* index_grid;
+	const uint32_t* brick_base;
+	const uint32_t* brick_arena; // 16 words per brick
+	int* load_queue;             // 3 ints per entry
+	uint32_t* load_queue_count;
+	uint32_t queue_cap;
+	int cells, cells_height; // bricks
+	int sg_xy, sg_xy2;       // supercells per axis, squared
+	float grid_size_f, grid_height_f;
+	int lod_distance_8x8x8, lod_distance_2x2x2;
+};
+
+// Per-launch constants computed on the host (launch_kernels:371-403 and the view-independent
+// part of the sky model, sunsky.cu:34-44,66-67).
+struct FrameConstants {
+	// camera (launch_kernels:384-385, primary_rays:154)
+	float right[3], up[3], dir[3], origin[3];
+	int campos[3];      // ivec3(camera.position / 8.f), kernel.cu:418
+	float focal3;       // focalDistance * ImGui_slider_hack(3), kernel.cu:191-192
+	float lens_radius;
+	// sky
+	float sun_direction[3];
+	float sun_angular_cos; // cos(1.5 deg), kernel.cu:374
+	float cone_extent;     // 1 - sun_angular_cos, kernel.cu:274
+	float sunE;            // SunIntensity(dot(sunDirection, up))
+	float rayleigh[3];     // rayleighAtX
+	float mie[3];          // mieAtX = totalMie(...) * mieCoefficient
+	float total[3];        // rayleighAtX + mieAtX
+	float mixf;            // clamp(pow(1 - dot(up, sunDirection), 5), 0, 1)
+	// frame
+	int width, height;
+	int spp, sample_base, max_bounces;
+	uint32_t base_frame;
+	uint32_t flags;
+	int band_rows, shard_rank, shard_count, local_rows;
+	// launch geometry
+	int tiles_x, tiles_y, stripe_w; // 16x16-pixel tiles; stripe_w = tile columns per XCD
+};
+
+struct DeviceCounters { // same order as bm_counters
+	unsigned long long v[8];
+};
+
+} // namespace bm

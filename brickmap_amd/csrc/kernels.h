@@ -1,0 +1,15 @@
+// kernels.h -- host-callable launchers implemented in trace.hip
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_types.h"
+
+namespace bm {
+void launch_trace(const DeviceScene& sc, const FrameConstants& fc, float* accum, uint32_t* dbg, DeviceCounters* counters, bool instrumented,
+				  hipStream_t stream);
+void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const uint32_t* indices_queue, uint32_t* arena, uint32_t count,
+				   hipStream_t stream);
+void launch_resolve(const float* accum, float* out, long long n, hipStream_t stream);
+void launch_debug_sincos(int n, const float* x, float* s, float* c, hipStream_t stream);
+void launch_debug_sky(const FrameConstants& fc, int n, const float* v, float* sun, float* sky, float* sunsky, hipStream_t stream);
+} // namespace bm

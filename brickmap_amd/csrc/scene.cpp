@@ -1,0 +1,413 @@
+// scene.cpp -- device residency, brick streaming and frame launch for one GPU.
+#include "scene.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "kernels.h"
+
+namespace bm {
+
+// ---------------------------------------------------------------- errors
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+const char* last_error() { return g_error.c_str(); }
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+	// the reference prints "cuda_assert: <string> <file> <line>" and exits (assert_cuda.cpp:3-13);
+	// the C-ABI reports instead and lets the caller decide.
+	char buf[512];
+	std::snprintf(buf, sizeof buf, "hip_assert: %s (%s) %s %d", hipGetErrorString(e), what, file, line);
+	set_error(buf);
+	return static_cast<int>(e);
+}
+
+// ---------------------------------------------------------------- small host vector helpers (GLM operation order)
+namespace {
+struct V3 {
+	float x, y, z;
+};
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline V3 cross3(V3 x, V3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
+inline V3 normalize3(V3 v) { return v * (1.0f / std::sqrt(dot3(v, v))); }
+constexpr float kPi = 3.1415926535897932f;
+
+// sunsky.cu:24-26 -- double literals make the tail of this expression double
+float sun_intensity(float zenith_cos) {
+	const float cutoff = kPi / 1.95f, steepness = 1.5f;
+	const double e = 1.0 - static_cast<double>(std::exp(-((cutoff - std::acos(zenith_cos)) / steepness)));
+	return static_cast<float>(1000.0 * (0.0 < e ? e : 0.0));
+}
+} // namespace
+
+int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp, FrameConstants* fc) {
+	if (!cam || !fp || !fc) { set_error("null argument"); return BM_EINVAL; }
+	if (fp->width <= 0 || fp->height <= 0 || fp->spp < 0 || fp->max_bounces < 0 || fp->band_rows <= 0 || fp->shard_count <= 0 ||
+		fp->shard_rank < 0 || fp->shard_rank >= fp->shard_count) {
+		set_error("bad frame parameters");
+		return BM_EINVAL;
+	}
+	std::memset(fc, 0, sizeof *fc);
+	const V3 dir{cam->direction[0], cam->direction[1], cam->direction[2]};
+	const V3 upv{cam->up[0], cam->up[1], cam->up[2]};
+	const float aspect = static_cast<float>(fp->width) / static_cast<float>(fp->height);
+	const V3 right = (normalize3(cross3(dir, upv)) * 1.5f) * aspect;   // launch_kernels:384
+	const V3 up = normalize3(cross3(right, dir)) * 1.5f;               // launch_kernels:385
+	fc->right[0] = right.x; fc->right[1] = right.y; fc->right[2] = right.z;
+	fc->up[0] = up.x; fc->up[1] = up.y; fc->up[2] = up.z;
+	for (int i = 0; i < 3; ++i) {
+		fc->dir[i] = cam->direction[i];
+		fc->origin[i] = cam->position[i];
+		fc->campos[i] = static_cast<int>(cam->position[i] / 8.f); // kernel.cu:418
+	}
+	fc->focal3 = cam->focal_distance * 3; // kernel.cu:191-192 (int 3)
+	fc->lens_radius = cam->lens_radius;
+
+	// sky constants (kernel.cu:374,393; sunsky.cu:14-18,28-30,34-44,66-67)
+	fc->sun_angular_cos = std::cos(1.5f * kPi / 180.f);
+	fc->cone_extent = 1.0f - fc->sun_angular_cos;
+	const float px = (fp->sun_position[0] - 0.0f) * 6.28f, py = (fp->sun_position[1] - 0.5f) * 3.14f;
+	const V3 sun = normalize3(V3{std::cos(px) * std::sin(py), std::sin(px) * std::sin(py), std::cos(py)});
+	fc->sun_direction[0] = sun.x; fc->sun_direction[1] = sun.y; fc->sun_direction[2] = sun.z;
+	const V3 sky_up{0.0f, 0.0f, 1.0f};
+	fc->sunE = sun_intensity(dot3(sun, sky_up));
+	const float rayleigh[3] = {5.176821E-6f, 1.2785348E-5f, 2.8530756E-5f};
+	const float lambda[3] = {680E-9f, 550E-9f, 450E-9f};
+	const float K[3] = {0.686f, 0.678f, 0.666f};
+	const float c = static_cast<float>((0.2 * static_cast<double>(1.f)) * 10E-18); // turbidity 1
+	const float mie_scale = 0.434f * c * kPi;
+	const float expo = static_cast<float>(static_cast<double>(4.0f) - 2.0);
+	for (int i = 0; i < 3; ++i) {
+		const float total_mie = (std::pow((2.0f * kPi) / lambda[i], expo) * mie_scale) * K[i];
+		fc->rayleigh[i] = rayleigh[i];
+		fc->mie[i] = total_mie * 0.005f;
+		fc->total[i] = fc->rayleigh[i] + fc->mie[i];
+	}
+	const float m = std::pow(1.0f - dot3(sky_up, sun), 5.0f);
+	fc->mixf = std::min(std::max(m, 0.0f), 1.0f);
+
+	fc->width = fp->width; fc->height = fp->height;
+	fc->spp = fp->spp; fc->sample_base = fp->sample_base; fc->max_bounces = fp->max_bounces;
+	fc->base_frame = fp->base_frame; fc->flags = fp->flags;
+	fc->band_rows = fp->band_rows; fc->shard_rank = fp->shard_rank; fc->shard_count = fp->shard_count;
+	fc->local_rows = bm_local_rows(fp);
+	fc->tiles_x = (fp->width + 15) / 16;
+	fc->tiles_y = (fc->local_rows + 15) / 16;
+	fc->stripe_w = (fc->tiles_x + 7) / 8;
+	return 0;
+}
+
+// ---------------------------------------------------------------- lifetime
+Scene::~Scene() {
+	hipSetDevice(device_);
+	free_device();
+	if (h_positions_) hipHostFree(h_positions_);
+	if (h_bricks_) hipHostFree(h_bricks_);
+	if (h_indices_) hipHostFree(h_indices_);
+	if (h_count_) hipHostFree(h_count_);
+	if (d_load_queue_) hipFree(d_load_queue_);
+	if (d_bricks_queue_) hipFree(d_bricks_queue_);
+	if (d_indices_queue_) hipFree(d_indices_queue_);
+	if (d_load_count_) hipFree(d_load_count_);
+	if (d_counters_) hipFree(d_counters_);
+	if (ev_start_) hipEventDestroy(ev_start_);
+	if (ev_stop_) hipEventDestroy(ev_stop_);
+	if (ev_upload_) hipEventDestroy(ev_upload_);
+	if (load_stream_) hipStreamDestroy(load_stream_);
+	if (kernel_stream_) hipStreamDestroy(kernel_stream_);
+}
+
+int Scene::init(int grid_size, int grid_height) {
+	if (!world.dims.set(grid_size, grid_height)) {
+		set_error("grid_size and grid_height must be positive multiples of 128 voxels");
+		return BM_EINVAL;
+	}
+	BM_HIP(hipSetDevice(device_));
+	BM_HIP(hipStreamCreateWithFlags(&load_stream_, hipStreamNonBlocking));
+	BM_HIP(hipStreamCreateWithFlags(&kernel_stream_, hipStreamNonBlocking));
+	BM_HIP(hipEventCreate(&ev_start_));
+	BM_HIP(hipEventCreate(&ev_stop_));
+	BM_HIP(hipEventCreateWithFlags(&ev_upload_, hipEventDisableTiming));
+	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_count_), sizeof(uint32_t), hipHostMallocDefault));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_load_count_), sizeof(uint32_t)));
+	BM_HIP(hipMemset(d_load_count_, 0, sizeof(uint32_t)));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_counters_), sizeof(DeviceCounters)));
+	BM_HIP(hipMemset(d_counters_, 0, sizeof(DeviceCounters)));
+	return alloc_queue();
+}
+
+int Scene::alloc_queue() {
+	BM_HIP(hipSetDevice(device_));
+	if (h_positions_) { hipHostFree(h_positions_); h_positions_ = nullptr; }
+	if (h_bricks_) { hipHostFree(h_bricks_); h_bricks_ = nullptr; }
+	if (h_indices_) { hipHostFree(h_indices_); h_indices_ = nullptr; }
+	if (d_load_queue_) { hipFree(d_load_queue_); d_load_queue_ = nullptr; }
+	if (d_bricks_queue_) { hipFree(d_bricks_queue_); d_bricks_queue_ = nullptr; }
+	if (d_indices_queue_) { hipFree(d_indices_queue_); d_indices_queue_ = nullptr; }
+	const size_t n = static_cast<size_t>(queue_cap_);
+	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_positions_), n * 3 * sizeof(int), hipHostMallocDefault)); // Scene.cpp:30
+	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_bricks_), n * sizeof(Brick), hipHostMallocDefault));      // Scene.cpp:31
+	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_indices_), n * sizeof(uint32_t), hipHostMallocDefault));  // Scene.cpp:32
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_load_queue_), n * 3 * sizeof(int)));                          // Scene.cpp:186
+	BM_HIP(hipMemset(d_load_queue_, 0, n * 3 * sizeof(int)));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_bricks_queue_), n * sizeof(Brick)));                          // Scene.cpp:189
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_indices_queue_), n * sizeof(uint32_t)));                      // Scene.cpp:190
+	BM_HIP(hipMemset(d_load_count_, 0, sizeof(uint32_t)));
+	view_.load_queue = d_load_queue_;
+	view_.load_queue_count = d_load_count_;
+	view_.queue_cap = static_cast<uint32_t>(queue_cap_);
+	return 0;
+}
+
+int Scene::set_lod(int lod8, int lod2) {
+	lod8_ = lod8;
+	lod2_ = lod2;
+	view_.lod_distance_8x8x8 = lod8;
+	view_.lod_distance_2x2x2 = lod2;
+	return 0;
+}
+
+int Scene::set_queue_capacity(int cap) {
+	if (cap <= 0) { set_error("queue capacity must be positive"); return BM_EINVAL; }
+	BM_HIP(hipSetDevice(device_));
+	BM_HIP(hipDeviceSynchronize());
+	queue_cap_ = cap;
+	return alloc_queue();
+}
+
+void Scene::free_device() {
+	if (d_index_grid_) hipFree(d_index_grid_);
+	if (d_brick_base_) hipFree(d_brick_base_);
+	if (d_arena_) hipFree(d_arena_);
+	d_index_grid_ = d_brick_base_ = d_arena_ = nullptr;
+	on_device_ = false;
+}
+
+// device half of Scene::generate (Scene.cpp:152-190): one flat index grid + one exact-fit brick arena
+// instead of 2 x supercells cudaMallocs and two pointer tables.
+int Scene::allocate_device() {
+	BM_HIP(hipSetDevice(device_));
+	free_device();
+	const WorldDims& d = world.dims;
+	brick_base_.assign(d.supercells, 0u);
+	uint64_t run = 0;
+	for (int i = 0; i < d.supercells; ++i) {
+		brick_base_[i] = static_cast<uint32_t>(run);
+		run += world.supercells[i].bricks.size();
+	}
+	if (run >= (1ull << 32)) { set_error("world has more than 2^32 bricks"); return BM_EINVAL; }
+	total_bricks_ = run;
+	const size_t index_bytes = static_cast<size_t>(d.supercells) * kCellsPerSupercell * sizeof(uint32_t);
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_index_grid_), index_bytes));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_brick_base_), static_cast<size_t>(d.supercells) * sizeof(uint32_t)));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_arena_), std::max<size_t>(64, static_cast<size_t>(total_bricks_) * sizeof(Brick))));
+	BM_HIP(hipMemcpy(d_brick_base_, brick_base_.data(), brick_base_.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	view_.index_grid = d_index_grid_;
+	view_.brick_base = d_brick_base_;
+	view_.brick_arena = d_arena_;
+	view_.cells = d.cells;
+	view_.cells_height = d.cells_height;
+	view_.sg_xy = d.supergrid_xy;
+	view_.sg_xy2 = d.supergrid_xy * d.supergrid_xy;
+	view_.grid_size_f = static_cast<float>(d.grid_size);
+	view_.grid_height_f = static_cast<float>(d.grid_height);
+	view_.lod_distance_8x8x8 = lod8_;
+	view_.lod_distance_2x2x2 = lod2_;
+	on_device_ = true;
+	return reset_residency();
+}
+
+int Scene::generate(int threads) {
+	world.generate(threads);
+	return allocate_device();
+}
+
+int Scene::generate_supercell(int sx, int sy, int sz) {
+	const WorldDims& d = world.dims;
+	if (sx < 0 || sy < 0 || sz < 0 || sx >= d.supergrid_xy || sy >= d.supergrid_xy || sz >= d.supergrid_z) {
+		set_error("supercell coordinates out of range");
+		return BM_EINVAL;
+	}
+	world.generate_supercell(sx, sy, sz);
+	return 0;
+}
+
+// reference initial state: every non-empty brick is "unloaded | lod", nothing resident (Scene.cpp:157-175)
+int Scene::reset_residency() {
+	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
+	BM_HIP(hipSetDevice(device_));
+	BM_HIP(hipDeviceSynchronize());
+	const WorldDims& d = world.dims;
+	std::vector<uint32_t> words(static_cast<size_t>(d.supercells) * kCellsPerSupercell);
+	for (int i = 0; i < d.supercells; ++i) {
+		HostSupercell& c = world.supercells[i];
+		c.resident = 0;
+		uint32_t* dst = &words[static_cast<size_t>(i) * kCellsPerSupercell];
+		for (int j = 0; j < kCellsPerSupercell; ++j)
+			dst[j] = (c.indices[j] & BM_BRICK_LOADED_BIT) ? (BM_BRICK_UNLOADED_BIT | (c.indices[j] & BM_BRICK_LOD_BITS)) : 0u;
+	}
+	BM_HIP(hipMemcpy(d_index_grid_, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	BM_HIP(hipMemset(d_load_count_, 0, sizeof(uint32_t)));
+	resident_bricks_ = 0;
+	upload_pending_ = false;
+	return 0;
+}
+
+int Scene::preload_all() {
+	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
+	BM_HIP(hipSetDevice(device_));
+	BM_HIP(hipDeviceSynchronize());
+	const WorldDims& d = world.dims;
+	std::vector<uint32_t> words(static_cast<size_t>(d.supercells) * kCellsPerSupercell);
+	for (int i = 0; i < d.supercells; ++i) {
+		HostSupercell& c = world.supercells[i];
+		std::memcpy(&words[static_cast<size_t>(i) * kCellsPerSupercell], c.indices.data(), kCellsPerSupercell * sizeof(uint32_t));
+		c.resident = static_cast<uint32_t>(c.bricks.size());
+		if (!c.bricks.empty())
+			BM_HIP(hipMemcpyAsync(d_arena_ + static_cast<size_t>(brick_base_[i]) * kBrickWords, c.bricks.data(), c.bricks.size() * sizeof(Brick),
+								  hipMemcpyHostToDevice, load_stream_));
+	}
+	BM_HIP(hipMemcpyAsync(d_index_grid_, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice, load_stream_));
+	BM_HIP(hipMemsetAsync(d_load_count_, 0, sizeof(uint32_t), load_stream_));
+	BM_HIP(hipStreamSynchronize(load_stream_));
+	resident_bricks_ = total_bricks_;
+	upload_pending_ = false;
+	return 0;
+}
+
+// ---------------------------------------------------------------- streaming
+int Scene::process_load_queue(uint32_t* serviced) {
+	if (serviced) *serviced = 0;
+	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
+	BM_HIP(hipSetDevice(device_));
+	// the frame that raised the requests must have finished (launch_kernels ends with cudaDeviceSynchronize, kernel.cu:431)
+	if (last_stream_) BM_HIP(hipStreamSynchronize(last_stream_));
+	BM_HIP(hipMemcpyAsync(h_count_, d_load_count_, sizeof(uint32_t), hipMemcpyDeviceToHost, load_stream_)); // Scene.cpp:202
+	BM_HIP(hipStreamSynchronize(load_stream_));
+	uint32_t count = std::min<uint32_t>(static_cast<uint32_t>(queue_cap_), *h_count_);                       // Scene.cpp:203
+	if (count == 0) return 0;
+	BM_HIP(hipMemcpyAsync(h_positions_, d_load_queue_, static_cast<size_t>(count) * 3 * sizeof(int), hipMemcpyDeviceToHost, load_stream_)); // :209
+	BM_HIP(hipStreamSynchronize(load_stream_));
+	const WorldDims& d = world.dims;
+	for (uint32_t i = 0; i < count; ++i) { // stage bricks + new index words (Scene.cpp:215-227)
+		const int px = h_positions_[3 * i], py = h_positions_[3 * i + 1], pz = h_positions_[3 * i + 2];
+		HostSupercell& c = world.supercells[d.supercell_id(px / kSupercell, py / kSupercell, pz / kSupercell)];
+		const uint32_t local = static_cast<uint32_t>((px % kSupercell) + (py % kSupercell) * kSupercell + (pz % kSupercell) * kSupercell * kSupercell);
+		const uint32_t word = c.indices[local];
+		std::memcpy(h_bricks_ + static_cast<size_t>(i) * kBrickWords, c.bricks[word & BM_BRICK_INDEX_BITS].data, sizeof(Brick));
+		h_indices_[i] = c.resident | BM_BRICK_LOADED_BIT | (word & BM_BRICK_LOD_BITS);
+		c.resident++;
+	}
+	// no pool growth (Scene.cpp:231-251): each supercell owns an exact-fit arena region, so `resident` can never overrun it
+	BM_HIP(hipMemcpyAsync(d_bricks_queue_, h_bricks_, static_cast<size_t>(count) * sizeof(Brick), hipMemcpyHostToDevice, load_stream_));    // :228
+	BM_HIP(hipMemcpyAsync(d_indices_queue_, h_indices_, static_cast<size_t>(count) * sizeof(uint32_t), hipMemcpyHostToDevice, load_stream_)); // :229
+	launch_upload(view_, d_bricks_queue_, d_indices_queue_, d_arena_, count, load_stream_); // kernel.cu:412
+	BM_HIP(hipGetLastError());
+	BM_HIP(hipMemsetAsync(d_load_count_, 0, sizeof(uint32_t), load_stream_));               // kernel.cu:413
+	BM_HIP(hipEventRecord(ev_upload_, load_stream_));
+	upload_pending_ = true;
+	resident_bricks_ += count;
+	if (serviced) *serviced = count;
+	return 0;
+}
+
+int Scene::dump(const char* path) { // Scene.cpp:254-258
+	std::ofstream file(path ? path : "dump.txt");
+	if (!file) { set_error("cannot open dump file"); return BM_EINVAL; }
+	for (const auto& c : world.supercells) file << c.resident << "\n";
+	return 0;
+}
+
+int Scene::info(bm_scene_info* out) {
+	if (!out) { set_error("null argument"); return BM_EINVAL; }
+	const WorldDims& d = world.dims;
+	std::memset(out, 0, sizeof *out);
+	out->grid_size = d.grid_size; out->grid_height = d.grid_height;
+	out->supergrid_xy = d.supergrid_xy; out->supergrid_z = d.supergrid_z; out->supercells = d.supercells;
+	out->queue_capacity = queue_cap_;
+	out->lod_distance_8x8x8 = lod8_; out->lod_distance_2x2x2 = lod2_;
+	out->generated = world.generated ? 1 : 0;
+	out->on_device = on_device_ ? 1 : 0;
+	out->total_bricks = world.generated ? world.total_bricks() : 0;
+	out->resident_bricks = resident_bricks_;
+	out->index_bytes = on_device_ ? static_cast<uint64_t>(d.supercells) * kCellsPerSupercell * 4 : 0;
+	out->brick_bytes = on_device_ ? total_bricks_ * 64 : 0;
+	return 0;
+}
+
+int Scene::device_indices(int supercell, uint32_t* out4096) {
+	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
+	if (supercell < 0 || supercell >= world.dims.supercells || !out4096) { set_error("bad supercell"); return BM_EINVAL; }
+	BM_HIP(hipSetDevice(device_));
+	BM_HIP(hipDeviceSynchronize());
+	BM_HIP(hipMemcpy(out4096, d_index_grid_ + static_cast<size_t>(supercell) * kCellsPerSupercell, kCellsPerSupercell * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+// ---------------------------------------------------------------- frame launch (launch_kernels, kernel.cu:366-439)
+int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum, uint32_t* dbg, hipStream_t stream) {
+	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
+	if (!accum) { set_error("null accumulation buffer"); return BM_EINVAL; }
+	FrameConstants fc;
+	if (int e = fill_frame_constants(cam, fp, &fc)) return e;
+	BM_HIP(hipSetDevice(device_));
+	if (!stream) stream = kernel_stream_;
+	if (upload_pending_) { // bricks uploaded on the load stream must be visible to this frame
+		BM_HIP(hipStreamWaitEvent(stream, ev_upload_, 0));
+		upload_pending_ = false;
+	}
+	const bool instrumented = dbg != nullptr || (fp->flags & BM_FLAG_COUNTERS);
+	BM_HIP(hipEventRecord(ev_start_, stream));
+	launch_trace(view_, fc, accum, dbg, (fp->flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr, instrumented, stream);
+	BM_HIP(hipGetLastError());
+	BM_HIP(hipEventRecord(ev_stop_, stream));
+	timed_ = true;
+	last_stream_ = stream;
+	return 0;
+}
+
+int Scene::resolve(const float* accum, float* out, long long n, hipStream_t stream) {
+	if (!accum || !out || n < 0) { set_error("bad argument"); return BM_EINVAL; }
+	BM_HIP(hipSetDevice(device_));
+	if (!stream) stream = kernel_stream_;
+	launch_resolve(accum, out, n, stream);
+	BM_HIP(hipGetLastError());
+	last_stream_ = stream;
+	return 0;
+}
+
+int Scene::synchronize() {
+	BM_HIP(hipSetDevice(device_));
+	BM_HIP(hipDeviceSynchronize());
+	return 0;
+}
+
+int Scene::last_render_ms(float* ms) {
+	if (!ms) { set_error("null argument"); return BM_EINVAL; }
+	if (!timed_) { set_error("no frame rendered yet"); return BM_ESTATE; }
+	BM_HIP(hipSetDevice(device_));
+	BM_HIP(hipEventSynchronize(ev_stop_));
+	BM_HIP(hipEventElapsedTime(ms, ev_start_, ev_stop_));
+	return 0;
+}
+
+int Scene::counters_read(bm_counters* out) {
+	if (!out) { set_error("null argument"); return BM_EINVAL; }
+	BM_HIP(hipSetDevice(device_));
+	BM_HIP(hipDeviceSynchronize());
+	static_assert(sizeof(bm_counters) == sizeof(DeviceCounters), "counter blocks must match");
+	BM_HIP(hipMemcpy(out, d_counters_, sizeof(DeviceCounters), hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int Scene::counters_reset() {
+	BM_HIP(hipSetDevice(device_));
+	BM_HIP(hipDeviceSynchronize());
+	BM_HIP(hipMemset(d_counters_, 0, sizeof(DeviceCounters)));
+	return 0;
+}
+
+} // namespace bm

@@ -1,0 +1,89 @@
+// scene.h -- device-resident brickmap scene for one GPU: residency, streaming, frame launch.
+// Mirrors the device half of the reference's Scene (src/Scene.cpp:29-36,152-194,200-258) and the
+// host orchestration of launch_kernels (src/kernel.cu:366-439).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/brickmap.h"
+#include "device_types.h"
+#include "world.h"
+
+namespace bm {
+
+// thread-local error slot behind bm_last_error_string()
+void set_error(const std::string& msg);
+const char* last_error();
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define BM_HIP(expr)                                                        \
+	do {                                                                    \
+		hipError_t bm_e_ = (expr);                                          \
+		if (bm_e_ != hipSuccess) return ::bm::hip_fail(bm_e_, #expr, __FILE__, __LINE__); \
+	} while (0)
+
+class Scene {
+public:
+	explicit Scene(int device) : device_(device) {}
+	~Scene();
+
+	int init(int grid_size, int grid_height); // Scene::Scene: streams + pinned staging
+	int set_lod(int lod8, int lod2);
+	int set_queue_capacity(int cap);
+	int generate(int threads);                // Scene::generate
+	int generate_supercell(int sx, int sy, int sz);
+	int preload_all();
+	int reset_residency();
+	int process_load_queue(uint32_t* serviced); // Scene::process_load_queue + upload
+	int dump(const char* path);
+	int info(bm_scene_info* out);
+	int device_indices(int supercell, uint32_t* out4096);
+	int render(const bm_camera* cam, const bm_frame_params* fp, float* accum, uint32_t* dbg, hipStream_t stream);
+	int resolve(const float* accum, float* out, long long n, hipStream_t stream);
+	int synchronize();
+	int last_render_ms(float* ms);
+	int counters_read(bm_counters* out);
+	int counters_reset();
+
+	World world;
+	int device() const { return device_; }
+
+	static int fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp, FrameConstants* fc);
+
+private:
+	int allocate_device();
+	void free_device();
+	int alloc_queue();
+
+	int device_;
+	bool on_device_ = false;
+	hipStream_t load_stream_ = nullptr, kernel_stream_ = nullptr; // Scene.cpp:34-35
+	hipEvent_t ev_start_ = nullptr, ev_stop_ = nullptr, ev_upload_ = nullptr;
+	bool timed_ = false, upload_pending_ = false;
+	hipStream_t last_stream_ = nullptr;
+
+	// device memory (DeviceScene view)
+	uint32_t* d_index_grid_ = nullptr;
+	uint32_t* d_brick_base_ = nullptr;
+	uint32_t* d_arena_ = nullptr;
+	int* d_load_queue_ = nullptr;
+	uint32_t* d_load_count_ = nullptr;
+	uint32_t* d_bricks_queue_ = nullptr;
+	uint32_t* d_indices_queue_ = nullptr;
+	DeviceCounters* d_counters_ = nullptr;
+	// pinned staging (Scene.cpp:30-32)
+	int* h_positions_ = nullptr;
+	uint32_t* h_bricks_ = nullptr;
+	uint32_t* h_indices_ = nullptr;
+	uint32_t* h_count_ = nullptr;
+
+	std::vector<uint32_t> brick_base_; // host copy of the prefix sums
+	uint64_t total_bricks_ = 0, resident_bricks_ = 0;
+	int queue_cap_ = 1024;                       // variables.h:35
+	int lod8_ = 600000, lod2_ = 100000;          // variables.h:24-27
+	DeviceScene view_{};
+};
+
+} // namespace bm

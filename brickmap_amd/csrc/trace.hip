@@ -1,0 +1,573 @@
+// trace.hip -- gfx950 path-trace kernels for the brickmap (hand-written HIP, wave64).
+//
+// One thread per pixel, one complete path per (pixel, sample): the reference's four wavefront
+// kernels primary_rays / extend / shade / connect (src/kernel.cu:154-346) are fused into one
+// launch that keeps the 64-byte RayQueue record (variables.h:43-52) in registers, and the
+// brick-grid DDA of src/voxel.cuh:135-261 walks a flat supercell-blocked index grid instead
+// of the reference's pointer table.  Per-ray arithmetic follows the reference operation for
+// operation (IEEE fp32, no contraction; see DESIGN.md "Numeric contract") so that hits are
+// bit-identical to the CPU oracle.
+//
+// Launch geometry: 256-thread workgroups = 16x16 pixel tiles, each wave an 8x8 pixel block
+// (coherent primary rays).  Workgroup b runs on XCD b%8 (observed dispatch rule), so tile
+// columns are dealt to XCDs in contiguous vertical stripes: every XCD's private 4 MiB L2 then
+// caches one wedge of the view frustum, and every XCD sees the same sky/terrain mix.
+#include <hip/hip_runtime.h>
+
+#include "detmath.h"
+#include "device_types.h"
+
+namespace bm {
+
+namespace {
+
+constexpr float kPi = 3.1415926535897932f;       // variables.h:3
+constexpr float kEpsilon = 0.001f;               // variables.h:22
+constexpr float kVeryFar = 1e20f;                // kernel.cu:12
+constexpr uint32_t kIndexBits = 0xFFFu;          // variables.h:29-33
+constexpr uint32_t kLodBits = 0xFF000u;
+constexpr uint32_t kLoadedBit = 0x80000000u;
+constexpr uint32_t kUnloadedBit = 0x40000000u;
+constexpr uint32_t kRequestedBit = 0x20000000u;
+
+struct f3 {
+	float x, y, z;
+};
+__device__ __forceinline__ f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator/(f3 a, f3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+// GLM forms: min(a,b) = (b<a)?b:a, max(a,b) = (a<b)?b:a, sign(x) = (0<x)-(x<0)
+__device__ __forceinline__ float gmin(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float gmax(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ int isign(float x) { return (0.f < x) - (x < 0.f); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 x, f3 y) {
+	return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+__device__ __forceinline__ f3 normalize(f3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
+__device__ __forceinline__ f3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+
+// ---- RNG (kernel.cu:19-37)
+__device__ __forceinline__ uint32_t random_int(uint32_t& seed) {
+	seed ^= seed << 13;
+	seed ^= seed >> 17;
+	seed ^= seed << 5;
+	return seed;
+}
+__device__ __forceinline__ float random_float(uint32_t& seed) { return random_int(seed) * 2.3283064365387e-10f; }
+__device__ __forceinline__ float random_float2(uint32_t& seed) { return (random_int(seed) >> 16) / 65535.0f; }
+
+// per-thread traversal counters (instrumented variant only)
+struct Tally {
+	uint32_t index_loads = 0, brick_tests = 0, byte_tests = 0, voxel_steps = 0, extend_rays = 0, shadow_rays = 0, requests = 0, paths = 0;
+};
+struct HitInfo {
+	int level = 0, brick_id = -1, sub_id = 0;
+};
+
+// ---- 8^3 bitmask DDA (voxel.cuh:79-133) and 2^3 LoD DDA (voxel.cuh:26-77): one body, N = 8 or 2.
+// `words` points at the 16-word brick (N == 8); `byte` is the LoD mask from the index word (N == 2).
+template <int N, bool DBG>
+__device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, f3& normal, float& distance, const uint32_t* __restrict__ words,
+											   uint32_t byte, int& sub_id, Tally& tally) {
+	int px = static_cast<int>(origin.x), py = static_cast<int>(origin.y), pz = static_cast<int>(origin.z);
+	const float cbx = dir.x > 0.f ? static_cast<float>(px + 1) : static_cast<float>(px);
+	const float cby = dir.y > 0.f ? static_cast<float>(py + 1) : static_cast<float>(py);
+	const float cbz = dir.z > 0.f ? static_cast<float>(pz + 1) : static_cast<float>(pz);
+	const int outx = dir.x > 0.f ? N : -1, outy = dir.y > 0.f ? N : -1, outz = dir.z > 0.f ? N : -1;
+	const int sx = isign(dir.x), sy = isign(dir.y), sz = isign(dir.z);
+	const float rx = dir.x == 0.0f ? 0.0f : 1.f / dir.x;
+	const float ry = dir.y == 0.0f ? 0.0f : 1.f / dir.y;
+	const float rz = dir.z == 0.0f ? 0.0f : 1.f / dir.z;
+	float tx = dir.x != 0.f ? (cbx - origin.x) * rx : 1000000.f;
+	float ty = dir.y != 0.f ? (cby - origin.y) * ry : 1000000.f;
+	float tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
+	const float dx = static_cast<float>(sx) * rx, dy = static_cast<float>(sy) * ry, dz = static_cast<float>(sz) * rz;
+	px %= N; py %= N; pz %= N;
+	distance = 0.f;
+	int axis = -1;
+	// at most 3N-2 cells lie on a line through an N^3 block; the bound only guards against NaN input
+	for (int guard = 0; guard < 3 * N + 2; ++guard) {
+		if (DBG) tally.voxel_steps++;
+		const int b = px + py * N + pz * N * N;
+		bool solid;
+		if (N == 8) solid = (words[(b >> 5) & 15] >> (b & 31)) & 1u;
+		else solid = (byte >> (b & 31)) & 1u;
+		if (solid) {
+			if (axis > -1) {
+				normal = mk(0.f, 0.f, 0.f);
+				if (axis == 0) { normal.x = -static_cast<float>(sx); distance = tx - dx; }
+				else if (axis == 1) { normal.y = -static_cast<float>(sy); distance = ty - dy; }
+				else { normal.z = -static_cast<float>(sz); distance = tz - dz; }
+			}
+			sub_id = b;
+			return true;
+		}
+		const bool mx = tx < ty && tx < tz;
+		const bool my = !mx && ty <= tx && ty < tz;
+		axis = (tx < ty) ? ((tx < tz) ? 0 : 2) : ((ty < tz) ? 1 : 2);
+		if (mx) { px += sx; if (px == outx) break; tx += dx; }
+		else if (my) { py += sy; if (py == outy) break; ty += dy; }
+		else { pz += sz; if (pz == outz) break; tz += dz; }
+	}
+	return false;
+}
+
+// ---- brick-grid DDA (voxel.cuh:135-261)
+template <bool DBG>
+__device__ __forceinline__ bool intersect_voxel(const DeviceScene& sc, const int campos_x, const int campos_y, const int campos_z, f3 origin,
+												const f3 dir, f3& normal, float& distance, HitInfo& info, Tally& tally) {
+	// intersect_aabb_branchless2 (voxel.cuh:13-24)
+	const f3 t1 = (mk(0.f, 0.f, 0.f) - origin) / dir;
+	const f3 t2 = (mk(sc.grid_size_f, sc.grid_size_f, sc.grid_height_f) - origin) / dir;
+	const f3 tMin = mk(gmin(t1.x, t2.x), gmin(t1.y, t2.y), gmin(t1.z, t2.z));
+	const f3 tMax = mk(gmax(t1.x, t2.x), gmax(t1.y, t2.y), gmax(t1.z, t2.z));
+	const float tminn = gmax(gmax(tMin.x, 0.f), gmax(tMin.y, tMin.z));
+	if (!(gmin(tMax.x, gmin(tMax.y, tMax.z)) > tminn)) return false;
+
+	if (tminn > 0) { // move the ray onto the box and derive the entry-face normal (voxel.cuh:142-155)
+		origin = origin + dir * tminn;
+		const float gs = sc.grid_size_f, gh = sc.grid_height_f;
+		const f3 scale = mk(1.f / (gs / gh), 1.f / (gs / gh), 1.f / (gh / gh));
+		const f3 center = mk(gs / 2.f, gs / 2.f, gh / 2.f);
+		const f3 d = center - origin;
+		f3 to_center = mk(fabsf(d.x), fabsf(d.y), fabsf(d.z)) * scale;
+		const f3 e = origin - center;
+		const f3 signs = mk(static_cast<float>(isign(e.x)), static_cast<float>(isign(e.y)), static_cast<float>(isign(e.z)));
+		to_center = to_center / gmax(to_center.x, gmax(to_center.y, to_center.z));
+		normal = signs * mk(truncf(to_center.x + 0.000001f), truncf(to_center.y + 0.000001f), truncf(to_center.z + 0.000001f));
+		origin = origin - normal * kEpsilon;
+	}
+	origin = origin / 8.f;
+	int px = static_cast<int>(origin.x), py = static_cast<int>(origin.y), pz = static_cast<int>(origin.z);
+	const int cells = sc.cells, cells_h = sc.cells_height;
+	if (px < 0 || px >= cells || py < 0 || py >= cells || pz < 0 || pz >= cells_h) return false;
+
+	const float cbx = dir.x > 0.f ? static_cast<float>(px + 1) : static_cast<float>(px);
+	const float cby = dir.y > 0.f ? static_cast<float>(py + 1) : static_cast<float>(py);
+	const float cbz = dir.z > 0.f ? static_cast<float>(pz + 1) : static_cast<float>(pz);
+	const int outx = dir.x > 0.f ? cells : -1, outy = dir.y > 0.f ? cells : -1, outz = dir.z > 0.f ? cells_h : -1;
+	const int sx = isign(dir.x), sy = isign(dir.y), sz = isign(dir.z);
+	const float rx = dir.x == 0.0f ? 0.0f : 1.f / dir.x;
+	const float ry = dir.y == 0.0f ? 0.0f : 1.f / dir.y;
+	const float rz = dir.z == 0.0f ? 0.0f : 1.f / dir.z;
+	float tx = dir.x != 0.f ? (cbx - origin.x) * rx : 1000000.f;
+	float ty = dir.y != 0.f ? (cby - origin.y) * ry : 1000000.f;
+	float tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
+	const float dx = static_cast<float>(sx) * rx, dy = static_cast<float>(sy) * ry, dz = static_cast<float>(sz) * rz;
+
+	int axis = -1;
+	// a well-formed ray makes at most 2*cells + cells_h steps; the bound only protects the GPU from NaN input
+	int guard = 4 * (2 * cells + cells_h) + 16;
+	while (guard-- > 0) {
+		// inside the loop 0 <= pos < cells, so >>4 and &15 equal the reference's signed /16 and %16
+		const int sci = (px >> 4) + (py >> 4) * sc.sg_xy + (pz >> 4) * sc.sg_xy2;
+		const uint32_t flat = (static_cast<uint32_t>(sci) << 12) + static_cast<uint32_t>((px & 15) + ((py & 15) << 4) + ((pz & 15) << 8));
+		const uint32_t index = sc.index_grid[flat];
+		if (DBG) tally.index_loads++;
+		if (index) {
+			float new_distance = 0.f;
+			if (axis != -1) {
+				normal = mk(0.f, 0.f, 0.f);
+				if (axis == 0) { normal.x = -static_cast<float>(sx); new_distance = tx - dx; }
+				else if (axis == 1) { normal.y = -static_cast<float>(sy); new_distance = ty - dy; }
+				else { normal.z = -static_cast<float>(sz); new_distance = tz - dz; }
+			}
+			const int ddx = campos_x - px, ddy = campos_y - py, ddz = campos_z - pz;
+			const int lod2 = ddx * ddx + ddy * ddy + ddz * ddz;
+			float sub_distance = 0.f;
+			if (DBG) info.brick_id = px + py * cells + pz * cells * cells;
+			if (lod2 > sc.lod_distance_8x8x8) {
+				distance = new_distance * 8.f + tminn;
+				if (DBG) { info.level = 0; info.sub_id = 0; }
+				return true;
+			} else if (lod2 > sc.lod_distance_2x2x2) {
+				if (DBG) tally.byte_tests++;
+				int sub = 0;
+				const f3 o2 = (origin + dir * new_distance) * 2.f - normal * 0.2f * kEpsilon;
+				if (intersect_grid<2, DBG>(o2, dir, normal, sub_distance, nullptr, (index & kLodBits) >> 12, sub, tally)) {
+					distance = new_distance * 8.f + sub_distance * 4.f + tminn;
+					if (DBG) { info.level = 1; info.sub_id = sub; }
+					return true;
+				}
+			} else if (index & kLoadedBit) {
+				if (DBG) tally.brick_tests++;
+				int sub = 0;
+				const uint32_t slot = sc.brick_base[sci] + (index & kIndexBits);
+				const uint32_t* brick = sc.brick_arena + (static_cast<size_t>(slot) << 4);
+				const f3 o8 = (origin + dir * new_distance) * 8.f - normal * kEpsilon;
+				if (intersect_grid<8, DBG>(o8, dir, normal, sub_distance, brick, 0u, sub, tally)) {
+					distance = new_distance * 8.f + sub_distance + tminn;
+					if (DBG) { info.level = 2; info.sub_id = sub; }
+					return true;
+				}
+			} else if (index & kUnloadedBit) {
+				// brick-request protocol (voxel.cuh:228-245): 32-bit atomics on the index word and the ring counter
+				const uint32_t old = atomicOr(&sc.index_grid[flat], kRequestedBit);
+				if (!(old & kRequestedBit)) {
+					const uint32_t load_index = atomicAdd(sc.load_queue_count, 1u);
+					if (load_index < sc.queue_cap) {
+						int* q = sc.load_queue + 3 * static_cast<size_t>(load_index);
+						q[0] = px; q[1] = py; q[2] = pz;
+						if (DBG) tally.requests++;
+					} else {
+						atomicAnd(&sc.index_grid[flat], ~kRequestedBit);
+					}
+				}
+				distance = new_distance * 8.f + tminn;
+				if (DBG) { info.level = 3; info.sub_id = 0; }
+				return true;
+			}
+		}
+		const bool mx = tx < ty && tx < tz;
+		const bool my = !mx && ty <= tx && ty < tz;
+		axis = (tx < ty) ? ((tx < tz) ? 0 : 2) : ((ty < tz) ? 1 : 2);
+		if (mx) { px += sx; if (px == outx) break; tx += dx; }
+		else if (my) { py += sy; if (py == outy) break; ty += dy; }
+		else { pz += sz; if (pz == outz) break; tz += dz; }
+	}
+	return false;
+}
+
+// ---- sky model (sunsky.cu:10-161); view-independent terms arrive precomputed in FrameConstants
+struct SkyTerms {
+	f3 Fex, somethingElse;
+	float cosViewSun;
+};
+__device__ __forceinline__ SkyTerms sky_terms(const FrameConstants& fc, f3 viewDir) {
+	const f3 sunDir = ld3(fc.sun_direction);
+	SkyTerms o;
+	o.cosViewSun = dot(viewDir, sunDir);
+	const float cosUpView = dot(mk(0.f, 0.f, 1.f), viewDir);
+	const float zenith = gmax(0.0f, cosUpView);
+	const float rayleighLen = 8.4E3f / zenith;
+	const float mieLen = 1.25E3f / zenith;
+	const f3 ray = ld3(fc.rayleigh), mie = ld3(fc.mie);
+	const f3 a = ray * rayleighLen + mie * mieLen;
+	o.Fex = mk(expf(-a.x), expf(-a.y), expf(-a.z));
+	// RayleighPhase (sunsky.cu:10-12) and hgPhase (:20-22) evaluate in double because of their double literals
+	const double c = static_cast<double>(o.cosViewSun);
+	const float rayleighPhase = static_cast<float>((3.0 / (16.0 * static_cast<double>(kPi))) * (1.0 + static_cast<double>(o.cosViewSun * o.cosViewSun)));
+	const double g = static_cast<double>(0.80f);
+	const double g2 = static_cast<double>(0.80f * 0.80f);
+	const double base = 1.0 - 2.0 * g * c + g2;
+	const float hg = static_cast<float>((1.0 / (4.0 * static_cast<double>(kPi))) * ((1.0 - g2) / (base * sqrt(base))));
+	const f3 light = ray * rayleighPhase + mie * hg;
+	o.somethingElse = (light / ld3(fc.total)) * fc.sunE;
+	return o;
+}
+__device__ __forceinline__ f3 sky_body(const FrameConstants& fc, const SkyTerms& t) {
+	f3 sky = t.somethingElse * mk(1.0f - t.Fex.x, 1.0f - t.Fex.y, 1.0f - t.Fex.z);
+	const f3 q = t.somethingElse * t.Fex;
+	const f3 p = mk(sqrtf(q.x), sqrtf(q.y), sqrtf(q.z)); // pow(x, 0.5)
+	const float a = fc.mixf;
+	return sky * mk(1.0f * (1.0f - a) + p.x * a, 1.0f * (1.0f - a) + p.y * a, 1.0f * (1.0f - a) + p.z * a);
+}
+__device__ __forceinline__ f3 sun_radiance(const FrameConstants& fc, f3 viewDir) { // sun(), sunsky.cu:32-74
+	const SkyTerms t = sky_terms(fc, viewDir);
+	// quirk kept: `sunAngularDiameterCos < (cosViewSunAngle ? 1.0 : 0.0)` tests cos != 0
+	const float sundisk = static_cast<double>(fc.sun_angular_cos) < (t.cosViewSun != 0.0f ? 1.0 : 0.0) ? 1.0f : 0.0f;
+	return ((t.Fex * (fc.sunE * 19000.0f)) * sundisk) * 0.01f;
+}
+__device__ __forceinline__ f3 sky_radiance(const FrameConstants& fc, f3 viewDir) { // sky(), sunsky.cu:76-114
+	const SkyTerms t = sky_terms(fc, viewDir);
+	return sky_body(fc, t) * (1.f * 0.01f);
+}
+__device__ __forceinline__ f3 sunsky_radiance(const FrameConstants& fc, f3 viewDir) { // sunsky(), sunsky.cu:116-161
+	if (fc.sun_angular_cos == 1.0f) return mk(1.0f, 0.0f, 0.0f);
+	const SkyTerms t = sky_terms(fc, viewDir);
+	const f3 sky = sky_body(fc, t);
+	const float e0 = fc.sun_angular_cos, e1 = fc.sun_angular_cos + 0.00002f;
+	const float s = gmin(gmax((t.cosViewSun - e0) / (e1 - e0), 0.0f), 1.0f);
+	const float sundisk = s * s * (3.0f - 2.0f * s);
+	const f3 sun = ((t.Fex * (fc.sunE * 19000.0f)) * sundisk) * 1E-5f;
+	return (sun + sky) * 0.01f;
+}
+
+// getConeSample (sunsky.cu:163-183)
+__device__ __forceinline__ f3 cone_sample(f3 dir, float extent, uint32_t& seed) {
+	dir = normalize(dir);
+	const f3 o = fabsf(dir.x) > fabsf(dir.z) ? mk(-dir.y, dir.x, 0.0f) : mk(0.0f, -dir.z, dir.y);
+	const f3 o1 = normalize(o);
+	const f3 o2 = normalize(cross(dir, o1));
+	float rx = random_float2(seed);
+	float ry = random_float2(seed);
+	rx = rx * 2.f * kPi;
+	ry = 1.0f - ry * extent;
+	const float oneminus = sqrtf(1.0f - ry * ry);
+	float s, c;
+	det_sincos(rx, s, c);
+	return (o1 * (c * oneminus) + o2 * (s * oneminus)) + dir * ry;
+}
+
+// hit-record hashing, identical to oracle.c (hmix / pack_normal)
+__device__ __forceinline__ uint32_t hmix(uint32_t h, uint32_t v) {
+	h ^= v;
+	h *= 16777619u;
+	h ^= h >> 15;
+	return h;
+}
+__device__ __forceinline__ uint32_t pack_normal(f3 n) {
+	const float c[3] = {n.x, n.y, n.z};
+	uint32_t r = 0;
+	for (int i = 0; i < 3; i++) {
+		const uint32_t code = c[i] == 0.0f ? 0u : (c[i] == 1.0f ? 1u : (c[i] == -1.0f ? 2u : 3u));
+		r |= code << (2 * i);
+	}
+	return r;
+}
+
+} // namespace
+
+template <bool DBG>
+__global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const FrameConstants fc, float4* __restrict__ accum,
+												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters) {
+	// XCD-aware tile assignment: vertical stripes of tile columns per XCD
+	const int b = blockIdx.x;
+	const int xcd = b & 7, j = b >> 3;
+	const int tile_x = xcd * fc.stripe_w + (j % fc.stripe_w);
+	const int tile_y = j / fc.stripe_w;
+	if (tile_x >= fc.tiles_x || tile_y >= fc.tiles_y) return;
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+	const int ly = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3); // row inside this shard's packed buffer
+	const int y = ((ly / fc.band_rows) * fc.shard_count + fc.shard_rank) * fc.band_rows + ly % fc.band_rows;
+	// lanes outside the image stay alive (they only skip the work) so that wave-wide reductions below are well defined
+	const bool valid = x < fc.width && ly < fc.local_rows && y < fc.height;
+
+	const uint32_t W = static_cast<uint32_t>(fc.width), H = static_cast<uint32_t>(fc.height);
+	const uint32_t p = static_cast<uint32_t>(y) * W + static_cast<uint32_t>(x); // global pixel index
+	const size_t local_pixel = static_cast<size_t>(ly) * W + static_cast<size_t>(x);
+	float4 acc = valid ? accum[local_pixel] : make_float4(0.f, 0.f, 0.f, 0.f);
+
+	const f3 cam_right = ld3(fc.right), cam_up = ld3(fc.up), cam_dir = ld3(fc.dir), cam_o = ld3(fc.origin);
+	const f3 sunDir = ld3(fc.sun_direction);
+	Tally tally;
+	uint32_t d0 = 0, d1 = 0, d2 = 0xFFFFFFFFu, d3 = 0, hseg = 2166136261u, hsh = 2166136261u, next = 0, nsh = 0;
+
+	const int spp = valid ? fc.spp : 0;
+	for (int s = 0; s < spp; ++s) {
+		const uint32_t slot = p + static_cast<uint32_t>(fc.sample_base + s) * W * H;
+		// ---- primary_rays (kernel.cu:157-200) for queue slot `slot`, start_position 0
+		uint32_t seed = (fc.base_frame * 147565741u) * 720898027u * slot;
+		f3 origin, direction;
+		{
+			// Random2DStratifiedSample (kernel.cu:40-61)
+			const int stratum = static_cast<int>(random_float(seed) * (16 + 0.99999f));
+			const int stratumX = stratum % 4, stratumY = (stratum / 4) % 4;
+			const float sx = 0.25f * stratumX + (random_float(seed) * 0.25f);
+			const float sy = 0.25f * stratumY + (random_float(seed) * 0.25f);
+			const float ppx = static_cast<float>(static_cast<uint32_t>(x)) - sx;
+			const float ppy = static_cast<float>(static_cast<uint32_t>(y)) - sy;
+			const float ni = (ppx / static_cast<float>(W)) - 0.5f;
+			const float nj = ((static_cast<float>(H) - ppy) / static_cast<float>(H)) - 0.5f;
+			const f3 to_focal = normalize(cam_dir + cam_right * ni + cam_up * nj);
+			const f3 convergence = cam_o + to_focal * fc.focal3;
+			const float l0 = random_float(seed); // canonical order: left to right
+			const float l1 = random_float(seed);
+			float lx = 0.f, lyy = 0.f;
+			{ // ConcentricSampleDisk (kernel.cu:85-103)
+				const float ox = 2.f * l0 - 1.f, oy = 2.f * l1 - 1.f;
+				if (!(ox == 0 && oy == 0)) {
+					float theta, r;
+					if (fabsf(ox) > fabsf(oy)) { r = ox; theta = kPi / 4 * (oy / ox); }
+					else { r = oy; theta = kPi / 2 - kPi / 4 * (ox / oy); }
+					float sn, cs;
+					det_sincos(theta, sn, cs);
+					lx = r * cs;
+					lyy = r * sn;
+				}
+			}
+			const float plx = fc.lens_radius * lx, ply = fc.lens_radius * lyy;
+			origin = cam_o + cam_right * plx + cam_up * ply;
+			direction = normalize(convergence - origin);
+		}
+		f3 throughput = mk(1.f, 1.f, 1.f), normal = mk(0.f, 0.f, 0.f);
+		int bounces = 0;
+		if (DBG) tally.paths++;
+
+		for (;;) {
+			// ---- extend (kernel.cu:226-238)
+			float distance = kVeryFar;
+			HitInfo info;
+			intersect_voxel<DBG>(sc, fc.campos[0], fc.campos[1], fc.campos[2], origin, direction, normal, distance, info, tally);
+			const bool is_hit = distance < kVeryFar;
+			if (DBG) {
+				tally.extend_rays++;
+				next++;
+				if (s == 0 && bounces == 0) {
+					d0 = is_hit ? __float_as_uint(distance) : 0u;
+					d1 = is_hit ? (pack_normal(normal) | (1u << 8) | (static_cast<uint32_t>(info.level) << 12)) : 0u;
+					d2 = is_hit ? static_cast<uint32_t>(info.brick_id) : 0xFFFFFFFFu;
+					d3 = is_hit ? static_cast<uint32_t>(info.sub_id) : 0u;
+				}
+				hseg = hmix(hseg, static_cast<uint32_t>(is_hit));
+				if (is_hit) {
+					hseg = hmix(hseg, __float_as_uint(distance));
+					hseg = hmix(hseg, pack_normal(normal) | (static_cast<uint32_t>(info.level) << 12));
+					hseg = hmix(hseg, static_cast<uint32_t>(info.brick_id));
+					hseg = hmix(hseg, static_cast<uint32_t>(info.sub_id));
+				}
+			}
+			if (fc.flags & 1u) { // BM_FLAG_PRIMARY_ONLY
+				if (!is_hit) {
+					const f3 c = throughput * sunsky_radiance(fc, direction);
+					acc.x += c.x; acc.y += c.y; acc.z += c.z;
+				}
+				acc.w += 1.f;
+				break;
+			}
+			// ---- shade (kernel.cu:242-325); frame = base_frame + bounce, queue slot = slot
+			const uint32_t frame = fc.base_frame + static_cast<uint32_t>(bounces);
+			uint32_t sseed = (frame * p * 147565741u) * 720898027u * slot;
+			if (!is_hit) {
+				const f3 c = throughput * (bounces == 0 ? sunsky_radiance(fc, direction) : sky_radiance(fc, direction));
+				acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.f;
+				break;
+			}
+			origin = origin + direction * distance;
+			origin = origin + normal * 2.f * kEpsilon;
+			throughput = throughput * mk(1.f, 1.f, 1.f);
+			const f3 sunSampleDir = cone_sample(sunDir, fc.cone_extent, sseed);
+			const float sunLight = dot(normal, sunSampleDir);
+			const bool cast = sunLight > 0.f;
+			f3 scolor = mk(0.f, 0.f, 0.f);
+			if (cast) scolor = ((throughput * sun_radiance(fc, sunSampleDir)) * sunLight) * 1E-5f;
+			const f3 shadow_origin = origin;
+			bool terminated = false;
+			if (bounces < fc.max_bounces) {
+				const float r1 = 2.f * kPi * random_float(sseed);
+				const float r2 = random_float(sseed);
+				const float r2s = sqrtf(r2);
+				// computeOrthonormalBasisNaive (kernel.cu:76-84)
+				f3 u = fabs(static_cast<double>(normal.x)) > .9 ? mk(0.0f, 1.0f, 0.0f) : mk(1.0f, 0.0f, 0.0f);
+				u = normalize(cross(u, normal));
+				const f3 v = cross(normal, u);
+				float sn, cs;
+				det_sincos(r1, sn, cs);
+				direction = normalize(((u * cs) * r2s + (v * sn) * r2s) + normal * sqrtf(1 - r2));
+				bounces++;
+			} else {
+				acc.w += 1.f; // kernel.cu:301
+				terminated = true;
+			}
+			// ---- connect (kernel.cu:328-346): runs after shade within the same reference frame
+			if (cast) {
+				f3 yn = mk(0.f, 0.f, 0.f);
+				float t = 0.f;
+				HitInfo sinfo;
+				const bool occluded = intersect_voxel<DBG>(sc, fc.campos[0], fc.campos[1], fc.campos[2], shadow_origin, sunSampleDir, yn, t, sinfo, tally);
+				if (DBG) {
+					tally.shadow_rays++;
+					nsh++;
+					hsh = hmix(hsh, static_cast<uint32_t>(occluded));
+					if (occluded) {
+						hsh = hmix(hsh, static_cast<uint32_t>(sinfo.brick_id));
+						hsh = hmix(hsh, static_cast<uint32_t>(sinfo.sub_id) | (static_cast<uint32_t>(sinfo.level) << 12));
+					}
+				}
+				if (!occluded) { acc.x += scolor.x; acc.y += scolor.y; acc.z += scolor.z; }
+			}
+			if (terminated) break;
+		}
+	}
+	if (valid) accum[local_pixel] = acc;
+
+	if (DBG) {
+		if (dbg && valid) {
+			uint32_t* d = dbg + local_pixel * 8;
+			d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = hseg; d[5] = hsh; d[6] = next | (nsh << 16); d[7] = tally.index_loads;
+		}
+		if (counters) { // wave-level sum, one atomic per wave and counter
+			unsigned long long v[8] = {tally.index_loads, tally.brick_tests, tally.byte_tests, tally.voxel_steps,
+									   tally.extend_rays, tally.shadow_rays, tally.requests, tally.paths};
+			for (int k = 0; k < 8; ++k) {
+				unsigned long long t = v[k];
+				for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+				if (lane == 0 && t) atomicAdd(&counters->v[k], t);
+			}
+		}
+	}
+}
+
+// upload kernel (kernel.cu:141-151): scatter staged bricks into the arena and publish their index words
+__global__ void upload_bricks(const DeviceScene sc, const uint32_t* __restrict__ bricks_queue, const uint32_t* __restrict__ indices_queue,
+							  uint32_t* __restrict__ arena_rw, uint32_t count) {
+	const uint32_t i = blockIdx.x * (blockDim.x / 16) + threadIdx.x / 16; // 16 lanes move one 64-byte brick
+	const uint32_t w = threadIdx.x & 15;
+	if (i >= count) return;
+	const int px = sc.load_queue[3 * i + 0], py = sc.load_queue[3 * i + 1], pz = sc.load_queue[3 * i + 2];
+	const int sci = (px / 16) + (py / 16) * sc.sg_xy + (pz / 16) * sc.sg_xy2;
+	const uint32_t local = static_cast<uint32_t>((px % 16) + (py % 16) * 16 + (pz % 16) * 256);
+	const uint32_t word = indices_queue[i];
+	const uint32_t slot = sc.brick_base[sci] + (word & kIndexBits);
+	arena_rw[(static_cast<size_t>(slot) << 4) + w] = bricks_queue[(static_cast<size_t>(i) << 4) + w];
+	if (w == 0) sc.index_grid[(static_cast<size_t>(sci) << 12) + local] = word; // plain store: clears unloaded + requested
+}
+
+// blit_onto_framebuffer (kernel.cu:348-364) into an offscreen float4 buffer
+__global__ void resolve_kernel(const float4* __restrict__ accum, float4* __restrict__ out, long long n) {
+	const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float4 c = accum[i];
+	float4 o;
+	o.x = powf(c.x / c.w, 1.f / 2.2f);
+	o.y = powf(c.y / c.w, 1.f / 2.2f);
+	o.z = powf(c.z / c.w, 1.f / 2.2f);
+	o.w = powf(1.f, 1.f / 2.2f);
+	out[i] = o;
+}
+
+__global__ void debug_sincos_kernel(int n, const float* __restrict__ x, float* __restrict__ s, float* __restrict__ c) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) det_sincos(x[i], s[i], c[i]);
+}
+
+__global__ void debug_sky_kernel(const FrameConstants fc, int n, const float* __restrict__ v, float* __restrict__ sun,
+								 float* __restrict__ sky, float* __restrict__ sunsky) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const f3 d = mk(v[3 * i], v[3 * i + 1], v[3 * i + 2]);
+	const f3 a = sun_radiance(fc, d), b = sky_radiance(fc, d), c = sunsky_radiance(fc, d);
+	sun[3 * i] = a.x; sun[3 * i + 1] = a.y; sun[3 * i + 2] = a.z;
+	sky[3 * i] = b.x; sky[3 * i + 1] = b.y; sky[3 * i + 2] = b.z;
+	sunsky[3 * i] = c.x; sunsky[3 * i + 1] = c.y; sunsky[3 * i + 2] = c.z;
+}
+
+// ---- host-callable launchers (kernels.h)
+void launch_trace(const DeviceScene& sc, const FrameConstants& fc, float* accum, uint32_t* dbg, DeviceCounters* counters, bool instrumented,
+				  hipStream_t stream) {
+	const int blocks = 8 * fc.stripe_w * fc.tiles_y;
+	if (blocks <= 0) return;
+	if (instrumented)
+		hipLaunchKernelGGL(trace_paths<true>, dim3(blocks), dim3(256), 0, stream, sc, fc, reinterpret_cast<float4*>(accum), dbg, counters);
+	else
+		hipLaunchKernelGGL(trace_paths<false>, dim3(blocks), dim3(256), 0, stream, sc, fc, reinterpret_cast<float4*>(accum), nullptr, nullptr);
+}
+
+void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const uint32_t* indices_queue, uint32_t* arena, uint32_t count,
+				   hipStream_t stream) {
+	if (count == 0) return;
+	const int per_block = 256 / 16;
+	hipLaunchKernelGGL(upload_bricks, dim3((count + per_block - 1) / per_block), dim3(256), 0, stream, sc, bricks_queue, indices_queue, arena, count);
+}
+
+void launch_resolve(const float* accum, float* out, long long n, hipStream_t stream) {
+	if (n <= 0) return;
+	hipLaunchKernelGGL(resolve_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const float4*>(accum),
+					   reinterpret_cast<float4*>(out), n);
+}
+
+void launch_debug_sincos(int n, const float* x, float* s, float* c, hipStream_t stream) {
+	hipLaunchKernelGGL(debug_sincos_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, x, s, c);
+}
+
+void launch_debug_sky(const FrameConstants& fc, int n, const float* v, float* sun, float* sky, float* sunsky, hipStream_t stream) {
+	hipLaunchKernelGGL(debug_sky_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, fc, n, v, sun, sky, sunsky);
+}
+
+} // namespace bm

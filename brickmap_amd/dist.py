@@ -1,0 +1,54 @@
+"""Multi-GPU sharding of the frame: interleaved row bands + one gather over RCCL/xGMI.
+
+The reference is single-GPU (no collective anywhere).  Pixels are independent, so
+the frame is split into row bands dealt round-robin to the ranks (band b belongs to rank
+b % world): each rank holds a full scene replica, renders its rows into a packed local float4
+buffer with RNG streams keyed on the *global* pixel index (so an N-rank image is bit-identical
+to the 1-rank image), and the only exchange is one gather of the packed bands to rank 0
+(`torch.distributed.gather` = grouped ncclSend/ncclRecv on the nccl/RCCL backend, one xGMI
+link per peer into the root).  No collective sits on the data path of the render itself.
+"""
+import numpy as np
+
+DEFAULT_BAND_ROWS = 16  # one row of 16x16 tiles
+
+
+def shard_rows(height, band_rows, rank, world):
+    """Global row indices owned by `rank`, in the order they are packed in its local buffer."""
+    rows = np.arange(height)
+    return rows[(rows // band_rows) % world == rank]
+
+
+def gather_frame(local, height, band_rows, group=None, dst=0):
+    """Gather every rank's packed rows ([local_rows, W, C] tensors, any backend) to `dst`.
+
+    Returns the assembled [height, W, C] frame on `dst` and None elsewhere.  Ranks may own
+    different numbers of rows (ragged last band); buffers are padded to the largest shard so a
+    single equal-sized gather can be used.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        assert local.shape[0] == height
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = [len(shard_rows(height, band_rows, r, world)) for r in range(world)]
+    assert local.shape[0] == counts[rank], f"rank {rank}: {local.shape[0]} local rows, expected {counts[rank]}"
+    max_rows = max(counts)
+    if local.shape[0] != max_rows:
+        pad = torch.zeros((max_rows - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send = torch.cat([local, pad], dim=0)
+    else:
+        send = local.contiguous()
+    if rank == dst:
+        recv = [torch.empty_like(send) for _ in range(world)]
+        dist.gather(send, gather_list=recv, dst=dst, group=group)
+        out = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        for r in range(world):
+            rows = torch.as_tensor(shard_rows(height, band_rows, r, world), device=local.device, dtype=torch.long)
+            if rows.numel():
+                out.index_copy_(0, rows, recv[r][: counts[r]])
+        return out
+    dist.gather(send, gather_list=None, dst=dst, group=group)
+    return None

@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's Scene / Camera / State / launch_kernels interface.
+
+Same names, argument meaning and call order as the reference's C++ (file:line into
+/root/reference/src): `Scene` (Scene.h:7-44), `Camera` (camera.h:3-24), `State` (state.h:5-34),
+`launch_kernels` (launch.h:6, kernel.cu:366-439).  Everything below the method bodies is the
+C-ABI of libbrickmap_hip.so; torch only provides device tensors and streams.
+"""
+import ctypes as C
+import math
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from ._lib import bm_camera, bm_counters, bm_frame_params, bm_scene_info, check
+
+
+def _f32(v):
+    return np.asarray(v, dtype=np.float32)
+
+
+def _normalize_f32(v):
+    """glm::normalize in fp32: v * (1 / sqrt((x*x + y*y) + z*z))."""
+    v = _f32(v)
+    d = np.float32(np.float32(v[0] * v[0] + v[1] * v[1]) + v[2] * v[2])
+    return v * (np.float32(1.0) / np.sqrt(d, dtype=np.float32))
+
+
+@dataclass
+class Camera:
+    """camera.h:3-24.  `handle_input` (GLFW keys/mouse) is out of scope: there is no window."""
+    position: tuple = (512.0, 512.0, 300.0)
+    direction: tuple = (1.0, 0.0, 0.0)
+    up: tuple = (0.0, 0.0, 1.0)
+    focalDistance: float = 1.0
+    lensRadius: float = 0.0
+    horizontal_angle: float = 0.0
+    vertical_angle: float = 0.0
+
+    def update(self):
+        """Camera::update (camera.cpp:48-54): direction from the two angles, then normalised."""
+        h, v = self.horizontal_angle, self.vertical_angle
+        d = _f32([math.cos(v) * math.sin(h), math.cos(v) * math.cos(h), math.sin(v)])
+        self.direction = tuple(float(x) for x in _normalize_f32(d))
+        return self
+
+    def to_c(self):
+        c = bm_camera()
+        c.position[:] = [float(x) for x in self.position]
+        c.direction[:] = [float(x) for x in self.direction]
+        c.up[:] = [float(x) for x in self.up]
+        c.focal_distance = float(self.focalDistance)
+        c.lens_radius = float(self.lensRadius)
+        return c
+
+
+@dataclass
+class FrameParams:
+    """Per-launch parameters the reference keeps as constexprs / statics (kernel.cu:13,369; variables.cpp:3)."""
+    width: int
+    height: int
+    spp: int = 1
+    sample_base: int = 0
+    max_bounces: int = 3
+    base_frame: int = 1
+    flags: int = 0
+    band_rows: int = 0  # 0 = whole image in one band
+    shard_rank: int = 0
+    shard_count: int = 1
+    sun_position: tuple = (0.05, 0.1)
+
+    def to_c(self):
+        p = bm_frame_params()
+        p.width, p.height, p.spp, p.sample_base = self.width, self.height, self.spp, self.sample_base
+        p.max_bounces, p.base_frame, p.flags = self.max_bounces, self.base_frame, self.flags
+        p.band_rows = self.band_rows if self.band_rows > 0 else self.height
+        p.shard_rank, p.shard_count = self.shard_rank, self.shard_count
+        p.sun_position[:] = [float(self.sun_position[0]), float(self.sun_position[1])]
+        return p
+
+
+def local_rows(params: FrameParams) -> int:
+    """Rows of the frame owned by this shard (bm_local_rows)."""
+    p = params.to_c()
+    return int(_lib.load().bm_local_rows(C.byref(p)))
+
+
+class Scene:
+    """Scene (Scene.h:7-44): CPU-built world + its residency on ONE GPU.
+
+    World dimensions are a constructor argument here (the reference's are constexpr, variables.h:7-8);
+    the defaults are the reference's 4096 x 4096 x 512 voxels.
+    """
+
+    def __init__(self, grid_size=4096, grid_height=512, device=0):
+        self._L = _lib.load()
+        self.device = device
+        h = C.c_void_p()
+        check(self._L.bm_scene_create(device, grid_size, grid_height, C.byref(h)))
+        self.gpuScene = h  # the reference passes Scene::GPUScene by value; here it is the scene handle
+        self.grid_size, self.grid_height = grid_size, grid_height
+
+    def close(self):
+        if getattr(self, "gpuScene", None):
+            self._L.bm_scene_destroy(self.gpuScene)
+            self.gpuScene = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference API
+    def generate(self, threads=None):
+        """Scene::generate (Scene.cpp:118-194)."""
+        check(self._L.bm_scene_generate(self.gpuScene, threads or os.cpu_count() or 1))
+        return self
+
+    def generate_supercell(self, start_x, start_y, start_z):
+        """Scene::generate_supercell (Scene.cpp:44-116), host only."""
+        check(self._L.bm_scene_generate_supercell(self.gpuScene, start_x, start_y, start_z))
+
+    def process_load_queue(self):
+        """Scene::process_load_queue (Scene.cpp:200-252) + upload (kernel.cu:141-151). Returns bricks serviced."""
+        n = C.c_uint32(0)
+        check(self._L.bm_scene_process_load_queue(self.gpuScene, C.byref(n)))
+        return int(n.value)
+
+    def dump(self, path="dump.txt"):
+        """Scene::dump (Scene.cpp:254-258)."""
+        check(self._L.bm_scene_dump(self.gpuScene, path.encode()))
+
+    # ---- additions the BASELINE configs need
+    def preload_all(self):
+        check(self._L.bm_scene_preload_all(self.gpuScene))
+        return self
+
+    def reset_residency(self):
+        check(self._L.bm_scene_reset_residency(self.gpuScene))
+        return self
+
+    def set_lod(self, lod_distance_8x8x8=600000, lod_distance_2x2x2=100000):
+        check(self._L.bm_scene_set_lod(self.gpuScene, lod_distance_8x8x8, lod_distance_2x2x2))
+        return self
+
+    def set_queue_capacity(self, capacity):
+        check(self._L.bm_scene_set_queue_capacity(self.gpuScene, capacity))
+        return self
+
+    def info(self):
+        i = bm_scene_info()
+        check(self._L.bm_scene_get_info(self.gpuScene, C.byref(i)))
+        return {name: int(getattr(i, name)) for name, _ in bm_scene_info._fields_}
+
+    def host_supercell(self, sc):
+        idx = np.zeros(4096, np.uint32)
+        n = C.c_uint32(0)
+        check(self._L.bm_scene_host_supercell(self.gpuScene, sc, idx.ctypes.data, C.byref(n), None, 0))
+        bricks = np.zeros((int(n.value), 16), np.uint32)
+        if n.value:
+            check(self._L.bm_scene_host_supercell(self.gpuScene, sc, None, None, bricks.ctypes.data, n.value))
+        return idx, bricks
+
+    def device_indices(self, sc):
+        idx = np.zeros(4096, np.uint32)
+        check(self._L.bm_scene_device_indices(self.gpuScene, sc, idx.ctypes.data))
+        return idx
+
+    def column_heights(self, sx, sy):
+        out = np.zeros((128, 128), np.float32)
+        check(self._L.bm_scene_column_heights(self.gpuScene, sx, sy, out.ctypes.data))
+        return out
+
+    def synchronize(self):
+        check(self._L.bm_synchronize(self.gpuScene))
+
+    def last_render_ms(self):
+        ms = C.c_float(0)
+        check(self._L.bm_last_render_ms(self.gpuScene, C.byref(ms)))
+        return float(ms.value)
+
+    def counters(self):
+        c = bm_counters()
+        check(self._L.bm_counters_read(self.gpuScene, C.byref(c)))
+        return c.as_dict()
+
+    def counters_reset(self):
+        check(self._L.bm_counters_reset(self.gpuScene))
+
+    def render(self, camera: Camera, params: FrameParams, accum, debug=None, stream=None):
+        """bm_render_frame: add params.spp paths per pixel into `accum` (torch CUDA float32 [rows, W, 4])."""
+        import torch
+        rows = local_rows(params)
+        assert accum.is_cuda and accum.dtype == torch.float32 and accum.is_contiguous()
+        assert accum.numel() == rows * params.width * 4, "accum must be [local_rows, width, 4]"
+        dbg_ptr = None
+        if debug is not None:
+            assert debug.is_cuda and debug.dtype == torch.int32 and debug.is_contiguous() and debug.numel() == rows * params.width * 8
+            dbg_ptr = C.c_void_p(debug.data_ptr())
+        if stream is None:
+            stream = torch.cuda.current_stream(accum.device).cuda_stream
+        cam_c, par_c = camera.to_c(), params.to_c()
+        check(self._L.bm_render_frame(self.gpuScene, C.byref(cam_c), C.byref(par_c), C.c_void_p(accum.data_ptr()), dbg_ptr,
+                                      C.c_void_p(stream)))
+
+    def resolve(self, accum, out=None, stream=None):
+        """blit_onto_framebuffer (kernel.cu:348-364) into an offscreen float4 tensor."""
+        import torch
+        if out is None:
+            out = torch.empty_like(accum)
+        if stream is None:
+            stream = torch.cuda.current_stream(accum.device).cuda_stream
+        check(self._L.bm_resolve(self.gpuScene, C.c_void_p(accum.data_ptr()), C.c_void_p(out.data_ptr()), accum.numel() // 4,
+                                 C.c_void_p(stream)))
+        return out
+
+
+class State:
+    """state.h:5-34 minus the wavefront queues and the GL interop: owns the float4 accumulation
+    ("blit") buffer of this process' shard of the frame."""
+
+    def __init__(self, screen_width, screen_height, device=0, band_rows=0, shard_rank=0, shard_count=1):
+        import torch
+        self.screen_width, self.screen_height = screen_width, screen_height
+        self.device = torch.device("cuda", device)
+        self.band_rows, self.shard_rank, self.shard_count = band_rows, shard_rank, shard_count
+        self._alloc()
+
+    def _alloc(self):
+        import torch
+        rows = local_rows(FrameParams(self.screen_width, self.screen_height, band_rows=self.band_rows,
+                                      shard_rank=self.shard_rank, shard_count=self.shard_count))
+        self.local_rows = rows
+        self.blit_buffer = torch.zeros((rows, self.screen_width, 4), dtype=torch.float32, device=self.device)
+
+    def screen_resize(self, screen_width, screen_height):
+        self.screen_width, self.screen_height = screen_width, screen_height
+        self._alloc()
+
+
+@dataclass
+class _LaunchStatics:
+    """The function-local statics of launch_kernels (kernel.cu:367-382)."""
+    first_time: bool = True
+    frame: int = 1
+    sample_base: int = 0
+    last: tuple = field(default_factory=tuple)
+    sun_position: tuple = (0.05, 0.1)
+    sun_position_changed: bool = True
+
+
+_statics = _LaunchStatics()
+
+
+def launch_kernels(state: State, blit_buffer, gpuScene: Scene, camera: Camera, spp=1, max_bounces=3, flags=0,
+                   sun_position=None, statics=None):
+    """launch_kernels (launch.h:6, kernel.cu:366-439) for the per-pixel design.
+
+    Differences forced by the redesign (DESIGN.md "Boundary"): no GL surface and no ray queues
+    (paths live in registers); one call traces `spp` complete paths per pixel instead of advancing
+    every in-flight path by one bounce.  As in the reference, a change of camera position /
+    direction / focal distance / lens radius or of the sun resets the accumulation buffer
+    (kernel.cu:387-403).  Returns 0 (the reference always returns cudaSuccess, kernel.cu:438).
+    """
+    st = statics or _statics
+    if sun_position is not None and tuple(sun_position) != st.sun_position:
+        st.sun_position = tuple(sun_position)
+        st.sun_position_changed = True
+    key = (tuple(camera.position), tuple(camera.direction), camera.focalDistance, camera.lensRadius)
+    reset_buffer = key != st.last
+    if st.sun_position_changed:
+        st.sun_position_changed = False
+        reset_buffer = True
+    if reset_buffer:
+        blit_buffer.zero_()
+        st.sample_base = 0
+    params = FrameParams(state.screen_width, state.screen_height, spp=spp, sample_base=st.sample_base, max_bounces=max_bounces,
+                         base_frame=1, flags=flags, band_rows=state.band_rows, shard_rank=state.shard_rank,
+                         shard_count=state.shard_count, sun_position=st.sun_position)
+    gpuScene.render(camera, params, blit_buffer)
+    st.sample_base += spp
+    st.frame += 1
+    st.first_time = False
+    st.last = key
+    return 0

@@ -1,0 +1,158 @@
+/*
+ * brickmap.h -- C-ABI of libbrickmap_hip.so: the MI355X (gfx950) brickmap path tracer.
+ *
+ * This is the drop-in boundary for ONE hot path of stijnherfst/BrickMap: the per-frame
+ * path-trace launch (reference src/launch.h:6, src/kernel.cu:366-439) plus the Scene
+ * object that feeds it (reference src/Scene.h:7-44, src/Scene.cpp:29-258).  Plain C types
+ * only; every entry point returns 0 on success or a non-zero hipError_t / BM_E* code and
+ * leaves a message for bm_last_error_string().  (The reference aborts the process inside
+ * its cuda() macro, src/assert_cuda.cpp:3-13; the C++ mirror in brickmap.hpp keeps that
+ * behaviour on top of these return codes.)
+ *
+ * Not thread-safe per scene; one scene per GPU (the reference is single-threaded,
+ * src/main.cpp:117-182).  All file:line citations are into the reference's src/.
+ */
+#ifndef BRICKMAP_H
+#define BRICKMAP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BM_API __attribute__((visibility("default")))
+
+/* error codes outside the hipError_t range */
+#define BM_EINVAL 10001 /* bad argument                                   */
+#define BM_ESTATE 10002 /* call made in the wrong state (e.g. not generated) */
+
+/* index-word layout, variables.h:29-33 */
+#define BM_BRICK_INDEX_BITS 0x00000FFFu
+#define BM_BRICK_LOD_BITS 0x000FF000u
+#define BM_BRICK_REQUESTED_BIT 0x20000000u
+#define BM_BRICK_UNLOADED_BIT 0x40000000u
+#define BM_BRICK_LOADED_BIT 0x80000000u
+
+/* frame flags */
+#define BM_FLAG_PRIMARY_ONLY 1u /* BASELINE config 1: extend the primary ray only          */
+#define BM_FLAG_COUNTERS 2u     /* accumulate the traversal counters (instrumented kernel)  */
+
+typedef struct bm_scene bm_scene; /* Scene + its GPUScene view (Scene.h:7-44), one GPU */
+
+/* camera.h:3-10 -- only the fields the kernels read (launch_kernels:384-385,416). */
+typedef struct bm_camera {
+	float position[3];    /* default (512,512,300)                      */
+	float direction[3];   /* unit; Camera::update, camera.cpp:48-54      */
+	float up[3];          /* default (0,0,1)                             */
+	float focal_distance; /* default 1                                   */
+	float lens_radius;    /* default 0                                   */
+} bm_camera;
+
+/*
+ * One launch = `spp` complete paths per pixel of this shard's rows (the reference advances
+ * every path one bounce per launch_kernels call; see DESIGN.md "Canonical path").
+ * Sample s of pixel p (p = y*width + x, global) draws its random numbers exactly as the
+ * reference does for queue slot  slot = p + (sample_base+s)*width*height  in frame
+ * `base_frame + bounce` (kernel.cu:165,252).
+ * Row sharding: global row y belongs to shard (y / band_rows) % shard_count; a shard's rows
+ * are packed in increasing y into its local buffer.  (height, 0, 1) renders everything.
+ */
+typedef struct bm_frame_params {
+	int32_t width, height;
+	int32_t spp;
+	int32_t sample_base;
+	int32_t max_bounces;  /* kernel.cu:13 MAX_BOUNCES = 3 -> at most 4 segments per path */
+	uint32_t base_frame;  /* kernel.cu:369 `frame` starts at 1                          */
+	uint32_t flags;       /* BM_FLAG_*                                                  */
+	int32_t band_rows, shard_rank, shard_count;
+	float sun_position[2]; /* variables.cpp:3 default (0.05, 0.1)                        */
+} bm_frame_params;
+
+typedef struct bm_scene_info {
+	int32_t grid_size, grid_height; /* voxels (variables.h:7-8, runtime here)            */
+	int32_t supergrid_xy, supergrid_z, supercells;
+	int32_t queue_capacity;         /* variables.h:35 brick_load_queue_size, default 1024 */
+	int32_t lod_distance_8x8x8, lod_distance_2x2x2; /* variables.h:24-27                  */
+	int32_t generated, on_device;
+	uint64_t total_bricks;          /* non-empty bricks on the host                      */
+	uint64_t resident_bricks;       /* bricks currently in the device arena              */
+	uint64_t index_bytes, brick_bytes; /* device allocations                             */
+} bm_scene_info;
+
+/* traversal counters (BM_FLAG_COUNTERS); same order as oracle/oracle.c orc_counters */
+typedef struct bm_counters {
+	uint64_t index_loads, brick_tests, byte_tests, voxel_steps, extend_rays, shadow_rays, requests, paths;
+} bm_counters;
+
+/* ---- errors (replaces assert_cuda.h:5 / assert_cuda.cpp:3-13) */
+BM_API const char* bm_last_error_string(void);
+BM_API int bm_device_count(int* count);
+BM_API int bm_device_name(int device, char* buf, size_t buflen, int* compute_units);
+
+/* ---- Scene (Scene.h:7-44) */
+/* Scene::Scene (Scene.cpp:29-36): pinned staging + load_stream/kernel_stream on `device`. */
+BM_API int bm_scene_create(int device, int grid_size, int grid_height, bm_scene** out);
+BM_API void bm_scene_destroy(bm_scene* scene);
+/* variables.h:24-27,35 made runtime; call before bm_scene_generate. */
+BM_API int bm_scene_set_lod(bm_scene* scene, int lod_distance_8x8x8, int lod_distance_2x2x2);
+BM_API int bm_scene_set_queue_capacity(bm_scene* scene, int capacity);
+/* Scene::generate (Scene.cpp:118-194): CPU world build on `threads` host threads, then the
+ * device allocations in the reference's initial state (nothing resident: unloaded|lod). */
+BM_API int bm_scene_generate(bm_scene* scene, int threads);
+/* Scene::generate_supercell (Scene.cpp:44-116): rebuild one supercell on the host (does not touch the device). */
+BM_API int bm_scene_generate_supercell(bm_scene* scene, int sx, int sy, int sz);
+/* BASELINE configs 1-2 "all bricks pre-loaded": device words = host words, arena = every host brick. */
+BM_API int bm_scene_preload_all(bm_scene* scene);
+/* back to the reference's initial residency (Scene.cpp:157-175) */
+BM_API int bm_scene_reset_residency(bm_scene* scene);
+/* Scene::process_load_queue (Scene.cpp:200-252) fused with the upload kernel of the next
+ * launch_kernels (kernel.cu:141-151,407-414): read the request ring, stage bricks in pinned
+ * memory, async H2D on the load stream, scatter into arena + index grid, reset the count.
+ * *serviced = number of bricks made resident. */
+BM_API int bm_scene_process_load_queue(bm_scene* scene, uint32_t* serviced);
+/* Scene::dump (Scene.cpp:254-258): one line per supercell = resident brick count. */
+BM_API int bm_scene_dump(bm_scene* scene, const char* path);
+BM_API int bm_scene_get_info(bm_scene* scene, bm_scene_info* info);
+/* test/inspection doors: host supercell content and the device index block */
+BM_API int bm_scene_host_supercell(bm_scene* scene, int supercell, uint32_t* indices4096, uint32_t* brick_count,
+                                   uint32_t* bricks, uint32_t brick_capacity);
+BM_API int bm_scene_device_indices(bm_scene* scene, int supercell, uint32_t* indices4096);
+BM_API int bm_scene_column_heights(bm_scene* scene, int sx, int sy, float* heights128x128);
+
+/* ---- State (state.h:5-34): the accumulation ("blit") buffer lives in device memory the
+ * caller owns; these helpers exist for callers without their own allocator. */
+BM_API int bm_buffer_alloc(int device, size_t bytes, void** dev_ptr);
+BM_API int bm_buffer_free(int device, void* dev_ptr);
+BM_API int bm_buffer_zero(int device, void* dev_ptr, size_t bytes, void* hip_stream);
+BM_API int bm_buffer_read(int device, void* host_dst, const void* dev_src, size_t bytes);
+BM_API int bm_buffer_write(int device, void* dev_dst, const void* host_src, size_t bytes);
+
+/* ---- launch_kernels (launch.h:6, kernel.cu:366-439) */
+/* rows of the frame owned by this shard */
+BM_API int bm_local_rows(const bm_frame_params* params);
+/* Adds `spp` paths per pixel into accum_dev (float4 per pixel, local_rows*width, rgb = sum of
+ * radiance, a = number of terminated paths; state.h:22, kernel.cu:301,319-322,341-343).
+ * debug_dev: NULL or 8 uint32 per pixel (hit records).  hip_stream: NULL = the
+ * scene's kernel stream.  Asynchronous with respect to the host. */
+BM_API int bm_render_frame(bm_scene* scene, const bm_camera* camera, const bm_frame_params* params,
+                           float* accum_dev, uint32_t* debug_dev, void* hip_stream);
+/* blit_onto_framebuffer (kernel.cu:348-364) into an offscreen float4 buffer: rgb/a, a=1, gamma 1/2.2 */
+BM_API int bm_resolve(bm_scene* scene, const float* accum_dev, float* out_dev, int64_t n_pixels, void* hip_stream);
+/* cudaDeviceSynchronize of launch_kernels:431 */
+BM_API int bm_synchronize(bm_scene* scene);
+/* duration of the most recent bm_render_frame kernel, measured with hipEvents on its stream (blocks) */
+BM_API int bm_last_render_ms(bm_scene* scene, float* ms);
+BM_API int bm_counters_read(bm_scene* scene, bm_counters* out);
+BM_API int bm_counters_reset(bm_scene* scene);
+
+/* ---- numeric-contract probes used by the parity tests (device side of detmath.h etc.) */
+BM_API int bm_debug_sincos(int device, int n, const float* x_host, float* sin_host, float* cos_host);
+BM_API int bm_debug_sky(int device, const float sun_position[2], int n, const float* viewdirs_host /*3n*/,
+                        float* sun_host /*3n*/, float* sky_host /*3n*/, float* sunsky_host /*3n*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRICKMAP_H */
