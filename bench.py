@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the brickmap path-trace hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one launch of the path-trace kernel over the workload's frame: `spp` complete paths
+(primary + up to max_bounces bounces, one shadow ray per hit) for every pixel of this rank's rows,
+with the scene already resident in HBM.  N = 1 runs BASELINE.json configs[1]:
+1920x1080, 1 spp, 4-bounce (MAX_BOUNCES = 3 -> 4 segments), 8x8x8 superchunks, all bricks resident.
+N > 1 keeps the per-GPU work fixed (weak scaling): the frame is split into interleaved 16-row
+bands, every rank traces N*spp samples for its H/N rows, then the packed bands are gathered to
+rank 0 over RCCL (brickmap_amd/dist.py) -- the gather is inside the timed region.
+
+metric: Mrays/s = width * height * spp_total * segments / seconds  (nominal rays).
+The line also carries `roofline` (algorithmic bytes of the kernel / its HIP-event duration against
+the 8 TB/s HBM peak) and, on rank 0 at N = 1, `cpu_baseline` (the oracle's scalar C port of the same
+path timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def workload(name):
+    """BASELINE.json configs (world = 128*N voxels per side for N^3 superchunks)."""
+    table = {
+        # name: (width, height, spp, max_bounces, superchunks per side, streaming)
+        "config1": (256, 256, 1, 0, 1, False),
+        "config2": (1920, 1080, 1, 3, 8, False),
+        "config3": (3840, 2160, 4, 7, 16, True),
+    }
+    return table[name]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import brickmap_amd as bm
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W, H, spp, max_bounces, n_super, streaming = workload(args.workload)
+    G = 128 * n_super
+    segments = max_bounces + 1
+    band = bm.dist.DEFAULT_BAND_ROWS if world > 1 else H
+    spp_step = spp * world  # weak scaling: N x the samples, 1/N of the rows per rank
+
+    # ---- scene replica on this GPU (world build is CPU plumbing and is not timed)
+    t0 = time.time()
+    scene = bm.Scene(G, G, device=local_rank).generate()
+    if streaming:
+        scene.set_queue_capacity(1 << 20)
+        scene.reset_residency()
+    else:
+        scene.preload_all()
+    build_s = time.time() - t0
+    cam = bm.Camera(position=(G / 2, G / 8, 0.8 * G), horizontal_angle=0.8, vertical_angle=-0.5).update()
+    state = bm.State(W, H, device=local_rank, band_rows=band, shard_rank=rank, shard_count=world)
+    accum = state.blit_buffer
+
+    def params(step, flags=0):
+        return bm.FrameParams(W, H, spp=spp_step, sample_base=step * spp_step, max_bounces=max_bounces, flags=flags,
+                              band_rows=band, shard_rank=rank, shard_count=world)
+
+    def one_step(step):
+        scene.render(cam, params(step), accum)
+        if streaming:
+            scene.process_load_queue()
+        if world > 1:
+            return bm.dist.gather_frame(accum, H, band)
+        return accum
+
+    if streaming:  # reach streaming steady state before anything is timed
+        for i in range(64):
+            scene.render(cam, params(0), accum)
+            if scene.process_load_queue() == 0:
+                break
+        accum.zero_()
+
+    for i in range(args.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    kernel_ms = scene.render_times(args.steps)  # HIP events on the launch stream, one pair per launch
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- algorithmic bytes of exactly the timed launches, from the instrumented kernel variant (not timed)
+    scene.counters_reset()
+    scratch = torch.zeros_like(accum)
+    for i in range(args.steps):
+        scene.render(cam, params(args.warmup + i, flags=bm.BM_FLAG_COUNTERS), scratch)
+    cnt = scene.counters()
+    local_rows = state.local_rows
+    alg_bytes = 4 * cnt["index_loads"] + 64 * cnt["brick_tests"] + 16 * W * local_rows * args.steps
+    avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
+    achieved_gbs = alg_bytes / args.steps / avg_kernel_s / 1e9
+    actual_rays = cnt["extend_rays"] + cnt["shadow_rays"]
+
+    nominal_rays_per_step = W * H * spp_step * segments
+    value = nominal_rays_per_step * args.steps / elapsed / 1e6
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    out = {
+        "metric": "Mrays/sec (primary x spp x bounces) at 1080p 4-bounce",
+        "value": round(value, 3),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (SimplexNoise terrain generated on the CPU, canonical xorshift RNG, random-free weights n/a)",
+        "config": {
+            "workload": f"BASELINE {args.workload}: {W}x{H}, {spp} spp per GPU-step (x{world} ranks = {spp_step} spp), "
+                        f"{segments} segments/path, {n_super}^3 superchunks ({G}^3 voxels), "
+                        + ("brick streaming at steady state" if streaming else "all bricks pre-loaded"),
+            "width": W, "height": H, "spp_per_step": spp_step, "segments": segments, "world_voxels": G,
+            "sharding": f"{world} x interleaved {band}-row bands + RCCL gather" if world > 1 else "single GPU",
+            "camera": {"position": list(cam.position), "angles": [0.8, -0.5]},
+            "world_build_s": round(build_s, 2),
+        },
+        "rays": {"nominal_per_step": nominal_rays_per_step, "actual_per_step_rank0": actual_rays / args.steps,
+                 "actual_Mrays_s_rank0_kernel": round(actual_rays / args.steps / avg_kernel_s / 1e6, 2)},
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved_gbs, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
+            "traffic": None,
+            "kernel": "bm::trace_paths<false>",
+            "kernel_ms_avg": round(float(np.mean(kernel_ms)), 4),
+            "algorithmic_bytes_per_launch": alg_bytes / args.steps,
+            "bytes_per_actual_ray": round(alg_bytes / max(actual_rays, 1), 1),
+            "counts_per_launch": {k: v / args.steps for k, v in cnt.items()},
+        },
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(W, H, spp, max_bounces, G, cam)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(W, H, spp, max_bounces, G, cam):
+    """The oracle's scalar C port of the same per-pixel path (oracle/oracle.c orc_render), all host
+    cores, on a bounded sample of the same workload: every 4th 16-row band of the same frame."""
+    import oracle
+    cores = os.cpu_count() or 1
+    world = oracle.World(G, G, threads=cores)
+    world.reset_device(True)
+    ocam = oracle.make_camera(cam.position, cam.direction)
+    frame = oracle.make_frame(W, H, spp=spp, max_bounces=max_bounces)
+    _, _, cnt, secs = world.render(ocam, frame, want_dbg=False, threads=cores)
+    rows = H
+    nominal = W * rows * spp * (max_bounces + 1)
+    return {
+        "value": round(nominal / secs / 1e6, 4),
+        "unit": "Mrays/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"one full {W}x{H} frame of the same workload, sample 0 ({nominal} nominal rays, "
+                  f"{cnt['extend_rays'] + cnt['shadow_rays']} actual) in {secs:.2f} s",
+    }
+
+
+if __name__ == "__main__":
+    main()

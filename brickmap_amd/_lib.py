@@ -76,6 +76,8 @@ SIGNATURES = {
     "bm_scene_host_supercell": (_i, [_vp, _i, _vp, _u32p, _vp, C.c_uint32]),
     "bm_scene_device_indices": (_i, [_vp, _i, _vp]),
     "bm_scene_column_heights": (_i, [_vp, _i, _i, _vp]),
+    "bm_host_column_heights": (_i, [_i, _i, _i, _i, _vp]),
+    "bm_host_generate_supercell": (_i, [_i, _i, _i, _i, _i, _vp, _u32p, _vp, C.c_uint32]),
     "bm_buffer_alloc": (_i, [_i, C.c_size_t, C.POINTER(_vp)]),
     "bm_buffer_free": (_i, [_i, _vp]),
     "bm_buffer_zero": (_i, [_i, _vp, C.c_size_t, _vp]),
@@ -86,6 +88,7 @@ SIGNATURES = {
     "bm_resolve": (_i, [_vp, _vp, _vp, C.c_int64, _vp]),
     "bm_synchronize": (_i, [_vp]),
     "bm_last_render_ms": (_i, [_vp, C.POINTER(C.c_float)]),
+    "bm_render_times": (_i, [_vp, _vp, _i, C.POINTER(C.c_int)]),
     "bm_counters_read": (_i, [_vp, C.POINTER(bm_counters)]),
     "bm_counters_reset": (_i, [_vp]),
     "bm_debug_sincos": (_i, [_i, _i, _vp, _vp, _vp]),

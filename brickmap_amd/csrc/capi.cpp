@@ -91,6 +91,35 @@ int bm_scene_column_heights(bm_scene* scene, int sx, int sy, float* heights) {
 	return 0;
 }
 
+int bm_host_column_heights(int grid_size, int grid_height, int sx, int sy, float* heights) {
+	bm::World w;
+	if (!heights || !w.dims.set(grid_size, grid_height) || sx < 0 || sy < 0 || sx >= w.dims.supergrid_xy || sy >= w.dims.supergrid_xy) {
+		set_error("bad world dimensions or column");
+		return BM_EINVAL;
+	}
+	w.column_heights(sx, sy, heights);
+	return 0;
+}
+
+int bm_host_generate_supercell(int grid_size, int grid_height, int sx, int sy, int sz, uint32_t* indices4096, uint32_t* brick_count,
+							   uint32_t* bricks, uint32_t brick_capacity) {
+	bm::World w;
+	if (!w.dims.set(grid_size, grid_height) || sx < 0 || sy < 0 || sz < 0 || sx >= w.dims.supergrid_xy || sy >= w.dims.supergrid_xy ||
+		sz >= w.dims.supergrid_z) {
+		set_error("bad world dimensions or supercell");
+		return BM_EINVAL;
+	}
+	w.generate_supercell(sx, sy, sz);
+	const bm::HostSupercell& c = w.supercells[w.dims.supercell_id(sx, sy, sz)];
+	if (indices4096) std::memcpy(indices4096, c.indices.data(), bm::kCellsPerSupercell * sizeof(uint32_t));
+	if (brick_count) *brick_count = static_cast<uint32_t>(c.bricks.size());
+	if (bricks) {
+		const size_t n = c.bricks.size() < brick_capacity ? c.bricks.size() : brick_capacity;
+		std::memcpy(bricks, c.bricks.data(), n * sizeof(bm::Brick));
+	}
+	return 0;
+}
+
 int bm_buffer_alloc(int device, size_t bytes, void** dev_ptr) {
 	if (!dev_ptr) { set_error("null argument"); return BM_EINVAL; }
 	BM_HIP(hipSetDevice(device));
@@ -140,6 +169,7 @@ int bm_resolve(bm_scene* scene, const float* accum_dev, float* out_dev, int64_t 
 }
 int bm_synchronize(bm_scene* scene) { BM_NEED(scene); return scene->impl.synchronize(); }
 int bm_last_render_ms(bm_scene* scene, float* ms) { BM_NEED(scene); return scene->impl.last_render_ms(ms); }
+int bm_render_times(bm_scene* scene, float* ms, int capacity, int* count) { BM_NEED(scene); return scene->impl.render_times(ms, capacity, count); }
 int bm_counters_read(bm_scene* scene, bm_counters* out) { BM_NEED(scene); return scene->impl.counters_read(out); }
 int bm_counters_reset(bm_scene* scene) { BM_NEED(scene); return scene->impl.counters_reset(); }
 

@@ -113,8 +113,10 @@ Scene::~Scene() {
 	if (d_indices_queue_) hipFree(d_indices_queue_);
 	if (d_load_count_) hipFree(d_load_count_);
 	if (d_counters_) hipFree(d_counters_);
-	if (ev_start_) hipEventDestroy(ev_start_);
-	if (ev_stop_) hipEventDestroy(ev_stop_);
+	for (int i = 0; i < kTimingRing; ++i) {
+		if (ev_start_[i]) hipEventDestroy(ev_start_[i]);
+		if (ev_stop_[i]) hipEventDestroy(ev_stop_[i]);
+	}
 	if (ev_upload_) hipEventDestroy(ev_upload_);
 	if (load_stream_) hipStreamDestroy(load_stream_);
 	if (kernel_stream_) hipStreamDestroy(kernel_stream_);
@@ -128,8 +130,10 @@ int Scene::init(int grid_size, int grid_height) {
 	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipStreamCreateWithFlags(&load_stream_, hipStreamNonBlocking));
 	BM_HIP(hipStreamCreateWithFlags(&kernel_stream_, hipStreamNonBlocking));
-	BM_HIP(hipEventCreate(&ev_start_));
-	BM_HIP(hipEventCreate(&ev_stop_));
+	for (int i = 0; i < kTimingRing; ++i) {
+		BM_HIP(hipEventCreate(&ev_start_[i]));
+		BM_HIP(hipEventCreate(&ev_stop_[i]));
+	}
 	BM_HIP(hipEventCreateWithFlags(&ev_upload_, hipEventDisableTiming));
 	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_count_), sizeof(uint32_t), hipHostMallocDefault));
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_load_count_), sizeof(uint32_t)));
@@ -284,7 +288,7 @@ int Scene::process_load_queue(uint32_t* serviced) {
 	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
 	BM_HIP(hipSetDevice(device_));
 	// the frame that raised the requests must have finished (launch_kernels ends with cudaDeviceSynchronize, kernel.cu:431)
-	if (last_stream_) BM_HIP(hipStreamSynchronize(last_stream_));
+	if (launches_ > 0) BM_HIP(hipStreamSynchronize(last_stream_)); // nullptr = the default stream
 	BM_HIP(hipMemcpyAsync(h_count_, d_load_count_, sizeof(uint32_t), hipMemcpyDeviceToHost, load_stream_)); // Scene.cpp:202
 	BM_HIP(hipStreamSynchronize(load_stream_));
 	uint32_t count = std::min<uint32_t>(static_cast<uint32_t>(queue_cap_), *h_count_);                       // Scene.cpp:203
@@ -354,17 +358,19 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 	FrameConstants fc;
 	if (int e = fill_frame_constants(cam, fp, &fc)) return e;
 	BM_HIP(hipSetDevice(device_));
-	if (!stream) stream = kernel_stream_;
+	// `stream` is used as given: nullptr is HIP's default stream (what the reference's <<<>>> launches use), which is
+	// ordered with the caller's other default-stream work (e.g. torch's fill kernels on the accumulation buffer).
 	if (upload_pending_) { // bricks uploaded on the load stream must be visible to this frame
 		BM_HIP(hipStreamWaitEvent(stream, ev_upload_, 0));
 		upload_pending_ = false;
 	}
 	const bool instrumented = dbg != nullptr || (fp->flags & BM_FLAG_COUNTERS);
-	BM_HIP(hipEventRecord(ev_start_, stream));
+	const int slot = static_cast<int>(launches_ % kTimingRing);
+	BM_HIP(hipEventRecord(ev_start_[slot], stream));
 	launch_trace(view_, fc, accum, dbg, (fp->flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr, instrumented, stream);
 	BM_HIP(hipGetLastError());
-	BM_HIP(hipEventRecord(ev_stop_, stream));
-	timed_ = true;
+	BM_HIP(hipEventRecord(ev_stop_[slot], stream));
+	launches_++;
 	last_stream_ = stream;
 	return 0;
 }
@@ -372,7 +378,6 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 int Scene::resolve(const float* accum, float* out, long long n, hipStream_t stream) {
 	if (!accum || !out || n < 0) { set_error("bad argument"); return BM_EINVAL; }
 	BM_HIP(hipSetDevice(device_));
-	if (!stream) stream = kernel_stream_;
 	launch_resolve(accum, out, n, stream);
 	BM_HIP(hipGetLastError());
 	last_stream_ = stream;
@@ -387,10 +392,25 @@ int Scene::synchronize() {
 
 int Scene::last_render_ms(float* ms) {
 	if (!ms) { set_error("null argument"); return BM_EINVAL; }
-	if (!timed_) { set_error("no frame rendered yet"); return BM_ESTATE; }
+	if (launches_ == 0) { set_error("no frame rendered yet"); return BM_ESTATE; }
 	BM_HIP(hipSetDevice(device_));
-	BM_HIP(hipEventSynchronize(ev_stop_));
-	BM_HIP(hipEventElapsedTime(ms, ev_start_, ev_stop_));
+	const int slot = static_cast<int>((launches_ - 1) % kTimingRing);
+	BM_HIP(hipEventSynchronize(ev_stop_[slot]));
+	BM_HIP(hipEventElapsedTime(ms, ev_start_[slot], ev_stop_[slot]));
+	return 0;
+}
+
+int Scene::render_times(float* ms, int capacity, int* count) {
+	if (!ms || !count || capacity <= 0) { set_error("bad argument"); return BM_EINVAL; }
+	BM_HIP(hipSetDevice(device_));
+	const long long have = std::min<long long>(launches_, kTimingRing);
+	const long long n = std::min<long long>(have, capacity);
+	for (long long k = 0; k < n; ++k) {
+		const int slot = static_cast<int>((launches_ - n + k) % kTimingRing);
+		BM_HIP(hipEventSynchronize(ev_stop_[slot]));
+		BM_HIP(hipEventElapsedTime(&ms[k], ev_start_[slot], ev_stop_[slot]));
+	}
+	*count = static_cast<int>(n);
 	return 0;
 }
 

@@ -44,6 +44,7 @@ public:
 	int resolve(const float* accum, float* out, long long n, hipStream_t stream);
 	int synchronize();
 	int last_render_ms(float* ms);
+	int render_times(float* ms, int capacity, int* count); // durations of the most recent launches, oldest first
 	int counters_read(bm_counters* out);
 	int counters_reset();
 
@@ -60,8 +61,11 @@ private:
 	int device_;
 	bool on_device_ = false;
 	hipStream_t load_stream_ = nullptr, kernel_stream_ = nullptr; // Scene.cpp:34-35
-	hipEvent_t ev_start_ = nullptr, ev_stop_ = nullptr, ev_upload_ = nullptr;
-	bool timed_ = false, upload_pending_ = false;
+	static constexpr int kTimingRing = 256; // hipEvent pairs around the most recent render launches
+	hipEvent_t ev_start_[kTimingRing] = {}, ev_stop_[kTimingRing] = {};
+	hipEvent_t ev_upload_ = nullptr;
+	long long launches_ = 0;
+	bool upload_pending_ = false;
 	hipStream_t last_stream_ = nullptr;
 
 	// device memory (DeviceScene view)

@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's Scene / Camera / State / launch_kernels interface.
 
 Same names, argument meaning and call order as the reference's C++ (file:line into
-/root/reference/src): `Scene` (Scene.h:7-44), `Camera` (camera.h:3-24), `State` (state.h:5-34),
+the reference checkout, src/): `Scene` (Scene.h:7-44), `Camera` (camera.h:3-24), `State` (state.h:5-34),
 `launch_kernels` (launch.h:6, kernel.cu:366-439).  Everything below the method bodies is the
 C-ABI of libbrickmap_hip.so; torch only provides device tensors and streams.
 """
@@ -84,6 +84,23 @@ def local_rows(params: FrameParams) -> int:
     """Rows of the frame owned by this shard (bm_local_rows)."""
     p = params.to_c()
     return int(_lib.load().bm_local_rows(C.byref(p)))
+
+
+def host_column_heights(grid_size, grid_height, sx, sy):
+    """Terrain heights of one supercell column from the product's CPU generator (no device needed)."""
+    out = np.zeros((128, 128), np.float32)
+    check(_lib.load().bm_host_column_heights(grid_size, grid_height, sx, sy, out.ctypes.data))
+    return out
+
+
+def host_generate_supercell(grid_size, grid_height, sx, sy, sz):
+    """(indices[4096], bricks[n,16]) of one supercell from the product's CPU generator (no device needed)."""
+    L = _lib.load()
+    idx = np.zeros(4096, np.uint32)
+    n = C.c_uint32(0)
+    bricks = np.zeros((4096, 16), np.uint32)
+    check(L.bm_host_generate_supercell(grid_size, grid_height, sx, sy, sz, idx.ctypes.data, C.byref(n), bricks.ctypes.data, 4096))
+    return idx, bricks[: n.value].copy()
 
 
 class Scene:
@@ -180,6 +197,13 @@ class Scene:
         ms = C.c_float(0)
         check(self._L.bm_last_render_ms(self.gpuScene, C.byref(ms)))
         return float(ms.value)
+
+    def render_times(self, capacity=256):
+        """Kernel durations (ms) of the most recent launches, oldest first (hipEvents on the launch stream)."""
+        ms = np.zeros(capacity, np.float32)
+        n = C.c_int(0)
+        check(self._L.bm_render_times(self.gpuScene, ms.ctypes.data, capacity, C.byref(n)))
+        return ms[: n.value].copy()
 
     def counters(self):
         c = bm_counters()

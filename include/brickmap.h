@@ -121,6 +121,11 @@ BM_API int bm_scene_host_supercell(bm_scene* scene, int supercell, uint32_t* ind
 BM_API int bm_scene_device_indices(bm_scene* scene, int supercell, uint32_t* indices4096);
 BM_API int bm_scene_column_heights(bm_scene* scene, int sx, int sy, float* heights128x128);
 
+/* host-only world-build doors (no device needed): the terrain generator behind Scene::generate */
+BM_API int bm_host_column_heights(int grid_size, int grid_height, int sx, int sy, float* heights128x128);
+BM_API int bm_host_generate_supercell(int grid_size, int grid_height, int sx, int sy, int sz, uint32_t* indices4096,
+                                      uint32_t* brick_count, uint32_t* bricks, uint32_t brick_capacity);
+
 /* ---- State (state.h:5-34): the accumulation ("blit") buffer lives in device memory the
  * caller owns; these helpers exist for callers without their own allocator. */
 BM_API int bm_buffer_alloc(int device, size_t bytes, void** dev_ptr);
@@ -134,8 +139,9 @@ BM_API int bm_buffer_write(int device, void* dev_dst, const void* host_src, size
 BM_API int bm_local_rows(const bm_frame_params* params);
 /* Adds `spp` paths per pixel into accum_dev (float4 per pixel, local_rows*width, rgb = sum of
  * radiance, a = number of terminated paths; state.h:22, kernel.cu:301,319-322,341-343).
- * debug_dev: NULL or 8 uint32 per pixel (hit records).  hip_stream: NULL = the
- * scene's kernel stream.  Asynchronous with respect to the host. */
+ * debug_dev: NULL or 8 uint32 per pixel (hit records).  hip_stream: the hipStream_t to
+ * launch on, used as given (NULL = the device's default stream, like the reference's <<<>>> launches).
+ * Asynchronous with respect to the host. */
 BM_API int bm_render_frame(bm_scene* scene, const bm_camera* camera, const bm_frame_params* params,
                            float* accum_dev, uint32_t* debug_dev, void* hip_stream);
 /* blit_onto_framebuffer (kernel.cu:348-364) into an offscreen float4 buffer: rgb/a, a=1, gamma 1/2.2 */
@@ -144,6 +150,8 @@ BM_API int bm_resolve(bm_scene* scene, const float* accum_dev, float* out_dev, i
 BM_API int bm_synchronize(bm_scene* scene);
 /* duration of the most recent bm_render_frame kernel, measured with hipEvents on its stream (blocks) */
 BM_API int bm_last_render_ms(bm_scene* scene, float* ms);
+/* durations (ms) of the most recent (up to 256) bm_render_frame kernels, oldest first; blocks until they finished */
+BM_API int bm_render_times(bm_scene* scene, float* ms, int capacity, int* count);
 BM_API int bm_counters_read(bm_scene* scene, bm_counters* out);
 BM_API int bm_counters_reset(bm_scene* scene);
 

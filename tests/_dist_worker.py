@@ -1,0 +1,43 @@
+"""Worker for tests/test_dist_gloo.py: one process per rank, gloo backend, CPU tensors.
+
+The sharding / gather logic (brickmap_amd/dist.py) is backend-agnostic; the per-rank renderer here
+is the CPU oracle standing in for the HIP kernel (allowed in tests), so that the N-rank frame can be
+checked against the 1-rank frame without a GPU."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from brickmap_amd import dist as bdist  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    W, H, band = 40, 70, 16  # ragged: 70 rows = 4 full bands + a 6-row tail
+    w = oracle.World(128, 128, threads=2)
+    w.reset_device(True)
+    cam = oracle.make_camera((64, 16, 102.4), oracle.camera_direction(0.8, -0.5))
+    full = np.zeros((H, W, 4), np.float32)
+    w.render(cam, oracle.make_frame(W, H, spp=2, band_rows=band, shard_rank=rank, shard_count=world), accum=full, want_dbg=False)
+    rows = bdist.shard_rows(H, band, rank, world)
+    local = torch.from_numpy(np.ascontiguousarray(full[rows]))
+    out = bdist.gather_frame(local, H, band, dst=0)
+    if rank == 0:
+        want, _, _, _ = w.render(cam, oracle.make_frame(W, H, spp=2), want_dbg=False)
+        assert out is not None and tuple(out.shape) == (H, W, 4)
+        assert np.array_equal(out.numpy(), want), "gathered N-rank frame differs from the 1-rank frame"
+        print("DIST_OK", world)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,361 @@
+"""Parity of the HIP path (through the C-ABI, brickmap_amd -> libbrickmap_hip.so) with the CPU oracle.
+
+Bar: hit records (distance bits, normal, brick id, voxel id, per-path hashes over every extend and
+shadow ray) BIT-EXACT; traversal counters exact; radiance within 1e-4 relative (the sky model calls
+expf/powf/acosf of the platform, the only non-bit-exact ingredient).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4  # north-star tolerance on per-pixel radiance
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def assert_radiance(got, want):
+    scale = np.maximum(np.abs(want), 1e-6)
+    err = np.abs(got - want) / scale
+    assert float(err.max()) <= RTOL, f"max relative radiance error {err.max():.3e}"
+
+
+def gpu_render(bm, torch, scene, cam, params, accum=None, want_dbg=True):
+    rows = bm.local_rows(params)
+    if accum is None:
+        accum = torch.zeros((rows, params.width, 4), dtype=torch.float32, device="cuda:0")
+    dbg = torch.zeros((rows, params.width, 8), dtype=torch.int32, device="cuda:0") if want_dbg else None
+    scene.render(cam, params, accum, debug=dbg)
+    torch.cuda.synchronize()
+    return accum.cpu().numpy(), (dbg.cpu().numpy().view(np.uint32) if want_dbg else None)
+
+
+def cameras(bm, orc, grid, pos=None, h=0.8, v=-0.5, direction=None):
+    pos = pos or (grid / 2, grid / 8, 0.8 * grid)
+    cam = bm.Camera(position=pos, horizontal_angle=h, vertical_angle=v).update()
+    if direction is not None:
+        cam.direction = tuple(float(x) for x in direction)
+    return cam, orc.make_camera(cam.position, cam.direction)
+
+
+@pytest.fixture(scope="module")
+def scene256(bm, torch_cuda):
+    s = bm.Scene(256, 256, device=0).generate()
+    s.preload_all()
+    yield s
+    s.close()
+
+
+def test_library_loaded_is_the_hip_extension(bm, torch_cuda):
+    from brickmap_amd import _lib
+    maps = open("/proc/self/maps").read()
+    assert _lib.LIB_PATH in maps, "the in-tree HIP extension is not the code that is running"
+
+
+def test_sincos_bit_exact(bm, orc, torch_cuda):
+    from brickmap_amd import _lib
+    x = np.concatenate([np.linspace(-8, 8, 200001), np.random.default_rng(1).random(100000) * 2 * np.pi]).astype(np.float32)
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    _lib.check(_lib.load().bm_debug_sincos(0, x.size, x.ctypes.data, s.ctypes.data, c.ctypes.data))
+    ws, wc = orc.sincos(x)
+    assert np.array_equal(s.view(np.uint32), ws.view(np.uint32)) and np.array_equal(c.view(np.uint32), wc.view(np.uint32))
+
+
+def test_sky_model_matches(bm, orc, torch_cuda):
+    from brickmap_amd import _lib
+    rng = np.random.default_rng(2)
+    v = rng.normal(size=(4096, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True).astype(np.float32)
+    for sun in [(0.05, 0.1), (0.3, 0.4), (0.7, 0.05)]:
+        out = [np.zeros_like(v) for _ in range(3)]
+        sp = np.float32(sun)
+        _lib.check(_lib.load().bm_debug_sky(0, sp.ctypes.data, len(v), v.ctypes.data, *[o.ctypes.data for o in out]))
+        want = [np.stack([orc.sky_probe(d, sun=sun)[k] for d in v]) for k in ("sun", "sky", "sunsky")]
+        for g, w in zip(out, want):
+            finite = np.isfinite(w)
+            assert np.array_equal(np.isfinite(g), finite)
+            np.testing.assert_allclose(g[finite], w[finite], rtol=2e-5, atol=1e-12)
+
+
+def test_world_on_device_matches_oracle(bm, orc, torch_cuda, scene256, world256):
+    info = scene256.info()
+    assert info["total_bricks"] == world256.total_bricks() and info["resident_bricks"] == info["total_bricks"]
+    assert info["index_bytes"] == world256.nsc * 16384 and info["brick_bytes"] == 64 * info["total_bricks"]
+    for sc in range(world256.nsc):
+        idx, bricks = scene256.host_supercell(sc)
+        assert np.array_equal(idx, world256.sc_indices(sc)) and np.array_equal(bricks, world256.sc_bricks(sc))
+        assert np.array_equal(scene256.device_indices(sc), world256.sc_indices(sc))
+
+
+def test_config1_primary_rays_golden(bm, orc, torch_cuda):
+    """BASELINE config 1 against the committed fixture: 256x256 primary-ray DDA into one superchunk."""
+    g = np.load(os.path.join(GOLDEN, "config1_primary.npz"))
+    scene = bm.Scene(int(g["grid"]), int(g["grid"]), device=0).generate().preload_all()
+    cam = bm.Camera(position=tuple(float(x) for x in g["cam_pos"]), direction=tuple(float(x) for x in g["cam_dir"]))
+    p = bm.FrameParams(int(g["width"]), int(g["height"]), spp=1, max_bounces=0, flags=bm.BM_FLAG_PRIMARY_ONLY | bm.BM_FLAG_COUNTERS)
+    scene.counters_reset()
+    acc, dbg = gpu_render(bm, torch_cuda, scene, cam, p)
+    assert np.array_equal(dbg[..., :4], g["hits"])
+    assert_radiance(acc, g["accum"])
+    cnt = scene.counters()
+    assert [cnt[k] for k in orc.COUNTER_NAMES] == list(g["counters"])
+    scene.close()
+
+
+def test_path4_golden_and_counters(bm, orc, torch_cuda, scene256):
+    g = np.load(os.path.join(GOLDEN, "path4_small.npz"))
+    cam = bm.Camera(position=tuple(float(x) for x in g["cam_pos"]), direction=tuple(float(x) for x in g["cam_dir"]))
+    p = bm.FrameParams(int(g["width"]), int(g["height"]), spp=int(g["spp"]), max_bounces=int(g["max_bounces"]), flags=bm.BM_FLAG_COUNTERS)
+    scene256.counters_reset()
+    acc, dbg = gpu_render(bm, torch_cuda, scene256, cam, p)
+    assert np.array_equal(dbg, g["dbg"])
+    assert_radiance(acc, g["accum"])
+    cnt = scene256.counters()
+    assert [cnt[k] for k in orc.COUNTER_NAMES] == list(g["counters"])
+
+
+CASES = [
+    # (name, width, height, spp, max_bounces, camera kwargs)
+    ("inside_down", 128, 96, 1, 3, dict()),
+    ("ragged_multi_spp", 75, 41, 3, 3, dict()),
+    ("eight_segments", 64, 48, 2, 7, dict()),
+    ("outside_world", 96, 64, 1, 3, dict(pos=(-300.0, -200.0, 500.0), h=0.9, v=-0.4)),
+    ("above_looking_down", 64, 64, 1, 3, dict(pos=(128.0, 128.0, 700.0), h=0.3, v=-1.5)),
+    ("all_sky", 48, 32, 1, 3, dict(v=1.2)),
+    ("axis_aligned", 64, 48, 1, 3, dict(pos=(10.5, 100.5, 140.5), direction=(1.0, 0.0, 0.0))),
+    ("grazing_boundary", 64, 48, 1, 3, dict(pos=(0.0, 0.0, 255.999), h=0.785, v=-0.3)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_paths_match_oracle(case, bm, orc, torch_cuda, scene256, world256):
+    _, W, H, spp, mb, ck = case
+    cam, ocam = cameras(bm, orc, 256, **ck)
+    world256.reset_device(True)
+    p = bm.FrameParams(W, H, spp=spp, max_bounces=mb, flags=bm.BM_FLAG_COUNTERS)
+    scene256.counters_reset()
+    acc, dbg = gpu_render(bm, torch_cuda, scene256, cam, p)
+    oacc, odbg, ocnt, _ = world256.render(ocam, orc.make_frame(W, H, spp=spp, max_bounces=mb))
+    assert np.array_equal(dbg, odbg), f"{np.count_nonzero((dbg != odbg).any(-1))} pixels with different hit records"
+    assert_radiance(acc, oacc)
+    assert scene256.counters() == ocnt
+    assert np.all(acc[..., 3] == spp)  # every path terminates exactly once
+
+
+def test_lens_and_focal_distance(bm, orc, torch_cuda, scene256, world256):
+    cam, _ = cameras(bm, orc, 256)
+    cam.lensRadius, cam.focalDistance = 0.75, 2.5
+    ocam = orc.make_camera(cam.position, cam.direction, focal_distance=2.5, lens_radius=0.75)
+    p = bm.FrameParams(64, 48, spp=2, max_bounces=3)
+    acc, dbg = gpu_render(bm, torch_cuda, scene256, cam, p)
+    oacc, odbg, _, _ = world256.render(ocam, orc.make_frame(64, 48, spp=2, max_bounces=3))
+    assert np.array_equal(dbg, odbg)
+    assert_radiance(acc, oacc)
+
+
+def test_sun_position_change(bm, orc, torch_cuda, scene256, world256):
+    cam, ocam = cameras(bm, orc, 256)
+    sun = (0.31, 0.22)
+    p = bm.FrameParams(64, 48, spp=1, max_bounces=3, sun_position=sun)
+    acc, dbg = gpu_render(bm, torch_cuda, scene256, cam, p)
+    oacc, odbg, _, _ = world256.render(ocam, orc.make_frame(64, 48, spp=1, max_bounces=3, sun=sun))
+    assert np.array_equal(dbg, odbg)
+    assert_radiance(acc, oacc)
+
+
+def test_lod_levels(bm, orc, torch_cuda):
+    """LoD thresholds shrunk so that all three levels (8^3 voxels, 2^3 byte, solid brick) occur in one frame."""
+    scene = bm.Scene(256, 256, device=0)
+    scene.set_lod(400, 60)
+    scene.generate().preload_all()
+    w = orc.World(256, 256)
+    w.set_lod(400, 60)
+    w.reset_device(True)
+    cam, ocam = cameras(bm, orc, 256)
+    p = bm.FrameParams(96, 64, spp=1, max_bounces=3, flags=bm.BM_FLAG_COUNTERS)
+    scene.counters_reset()
+    acc, dbg = gpu_render(bm, torch_cuda, scene, cam, p)
+    oacc, odbg, ocnt, _ = w.render(ocam, orc.make_frame(96, 64, spp=1, max_bounces=3))
+    levels = set(((odbg[..., 1] >> 12) & 0xF)[odbg[..., 1] != 0].tolist())
+    assert {0, 1, 2} <= levels, f"test frame does not exercise all LoD levels: {levels}"
+    assert np.array_equal(dbg, odbg)
+    assert_radiance(acc, oacc)
+    assert scene.counters() == ocnt and ocnt["byte_tests"] > 0
+    scene.close()
+
+
+def test_non_cubic_world(bm, orc, torch_cuda):
+    scene = bm.Scene(384, 128, device=0).generate().preload_all()
+    w = orc.World(384, 128)
+    w.reset_device(True)
+    cam = bm.Camera(position=(200.0, 40.0, 110.0), horizontal_angle=0.6, vertical_angle=-0.35).update()
+    ocam = orc.make_camera(cam.position, cam.direction)
+    acc, dbg = gpu_render(bm, torch_cuda, scene, cam, bm.FrameParams(80, 60, spp=1, max_bounces=3))
+    oacc, odbg, _, _ = w.render(ocam, orc.make_frame(80, 60, spp=1, max_bounces=3))
+    assert np.array_equal(dbg, odbg)
+    assert_radiance(acc, oacc)
+    scene.close()
+
+
+def test_streaming_first_frame_and_steady_state(bm, orc, torch_cuda):
+    """Reference initial residency: nothing loaded.  Frame 1 treats every unloaded brick as solid and
+    requests it (deterministic image, deterministic request SET); at steady state the image equals
+    the all-resident image."""
+    G, W, H = 256, 96, 64
+    scene = bm.Scene(G, G, device=0)
+    scene.set_queue_capacity(1 << 16)
+    scene.generate()
+    w = orc.World(G, G)
+    w.set_queue_cap(1 << 16)
+    w.reset_device(False)
+    cam, ocam = cameras(bm, orc, G)
+    p = bm.FrameParams(W, H, spp=1, max_bounces=3, flags=bm.BM_FLAG_COUNTERS)
+    scene.counters_reset()
+    acc, dbg = gpu_render(bm, torch_cuda, scene, cam, p)
+    oacc, odbg, ocnt, _ = w.render(ocam, orc.make_frame(W, H, spp=1, max_bounces=3))
+    assert np.array_equal(dbg, odbg)
+    assert_radiance(acc, oacc)
+    assert scene.counters() == ocnt and ocnt["requests"] > 0 and ocnt["brick_tests"] == 0
+    # requested-bit sets agree supercell by supercell
+    for sc in range(w.nsc):
+        assert np.array_equal(scene.device_indices(sc), w.sc_dev_indices(sc))
+    n_gpu, n_cpu = scene.process_load_queue(), w.process_load_queue()
+    w.upload()
+    assert n_gpu == n_cpu == ocnt["requests"]
+    assert scene.info()["resident_bricks"] == n_gpu
+    for _ in range(64):
+        gpu_render(bm, torch_cuda, scene, cam, p, want_dbg=False)
+        if scene.process_load_queue() == 0:
+            break
+    else:
+        pytest.fail("streaming did not reach a steady state")
+    acc_s, dbg_s = gpu_render(bm, torch_cuda, scene, cam, bm.FrameParams(W, H, spp=1, max_bounces=3))
+    scene.preload_all()
+    acc_r, dbg_r = gpu_render(bm, torch_cuda, scene, cam, bm.FrameParams(W, H, spp=1, max_bounces=3))
+    assert np.array_equal(dbg_s, dbg_r) and np.array_equal(acc_s, acc_r)
+    scene.dump("/tmp/bm_dump.txt")
+    assert len(open("/tmp/bm_dump.txt").read().split()) == w.nsc
+    scene.close()
+
+
+def test_request_ring_overflow(bm, orc, torch_cuda):
+    """A frame that wants more bricks than the ring holds gets exactly `capacity` serviced; the losers'
+    request bits are cleared again (voxel.cuh:234-240) so that they can ask again next frame."""
+    scene = bm.Scene(256, 256, device=0)
+    assert scene.info()["queue_capacity"] == 1024  # reference ring size, variables.h:35
+    scene.set_queue_capacity(64)
+    scene.generate()
+    cam, _ = cameras(bm, orc, 256)
+    p = bm.FrameParams(256, 192, spp=1, max_bounces=3)
+    gpu_render(bm, torch_cuda, scene, cam, p, want_dbg=False)
+    requested = sum(int(np.count_nonzero(scene.device_indices(sc) & bm.BRICK_REQUESTED_BIT)) for sc in range(8))
+    assert requested == 64
+    assert scene.process_load_queue() == 64
+    requested = sum(int(np.count_nonzero(scene.device_indices(sc) & bm.BRICK_REQUESTED_BIT)) for sc in range(8))
+    loaded = sum(int(np.count_nonzero(scene.device_indices(sc) & bm.BRICK_LOADED_BIT)) for sc in range(8))
+    assert loaded == 64 and requested == 0
+    total = 64
+    for _ in range(200):
+        gpu_render(bm, torch_cuda, scene, cam, p, want_dbg=False)
+        n = scene.process_load_queue()
+        total += n
+        if n == 0:
+            break
+    assert n == 0 and total == scene.info()["resident_bricks"] > 64
+    scene.close()
+
+
+def test_sharded_equals_unsharded_and_accumulation(bm, orc, torch_cuda, scene256):
+    torch = torch_cuda
+    cam, _ = cameras(bm, orc, 256)
+    W, H = 100, 70
+    full, dfull = gpu_render(bm, torch, scene256, cam, bm.FrameParams(W, H, spp=2, max_bounces=3))
+    out = np.zeros_like(full)
+    for r in range(3):
+        p = bm.FrameParams(W, H, spp=2, max_bounces=3, band_rows=16, shard_rank=r, shard_count=3)
+        acc, _ = gpu_render(bm, torch, scene256, cam, p)
+        out[bm.dist.shard_rows(H, 16, r, 3)] = acc
+    assert np.array_equal(out, full)
+    # two launches of 1 spp == one launch of 2 spp (same per-pixel accumulation order)
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    for s in range(2):
+        scene256.render(cam, bm.FrameParams(W, H, spp=1, sample_base=s, max_bounces=3), acc)
+    torch.cuda.synchronize()
+    assert np.array_equal(acc.cpu().numpy(), full)
+
+
+def test_launch_kernels_mirror_and_resolve(bm, orc, torch_cuda, scene256, world256):
+    """The reference-shaped call sequence: State + launch_kernels per frame, then the resolve ("blit")."""
+    torch = torch_cuda
+    from brickmap_amd.host import _LaunchStatics
+    st = _LaunchStatics()
+    state = bm.State(64, 48, device=0)
+    cam, ocam = cameras(bm, orc, 256)
+    for _ in range(3):
+        assert bm.launch_kernels(state, state.blit_buffer, scene256, cam, spp=1, statics=st) == 0
+    torch.cuda.synchronize()
+    oacc, _, _, _ = world256.render(ocam, orc.make_frame(64, 48, spp=3, max_bounces=3), want_dbg=False)
+    assert_radiance(state.blit_buffer.cpu().numpy(), oacc)
+    out = scene256.resolve(state.blit_buffer)
+    torch.cuda.synchronize()
+    want = np.zeros_like(oacc)
+    orc.lib().orc_resolve(oacc.ctypes.data, want.ctypes.data, 64 * 48)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=2e-4)
+    # moving the camera resets the accumulation (kernel.cu:387-403)
+    cam2 = bm.Camera(position=(130.0, 40.0, 200.0), horizontal_angle=0.7, vertical_angle=-0.5).update()
+    bm.launch_kernels(state, state.blit_buffer, scene256, cam2, spp=1, statics=st)
+    torch.cuda.synchronize()
+    assert float(state.blit_buffer[..., 3].max()) == 1.0
+
+
+def test_full_size_config2_properties(bm, orc, torch_cuda):
+    """BASELINE config 2 at full size (1920x1080, 4 segments, 8^3 superchunks): size-independent
+    properties plus an exact comparison with the oracle on every 60th row."""
+    torch = torch_cuda
+    G, W, H = 1024, 1920, 1080
+    scene = bm.Scene(G, G, device=0).generate().preload_all()
+    cam, ocam = cameras(bm, orc, G)
+    p = bm.FrameParams(W, H, spp=1, max_bounces=3, flags=bm.BM_FLAG_COUNTERS)
+    scene.counters_reset()
+    acc, dbg = gpu_render(bm, torch, scene, cam, p)
+    cnt = scene.counters()
+    assert np.all(acc[..., 3] == 1.0) and np.all(np.isfinite(acc))
+    assert cnt["paths"] == W * H and cnt["paths"] <= cnt["extend_rays"] <= 4 * cnt["paths"] and cnt["shadow_rays"] <= cnt["extend_rays"]
+    assert int((dbg[..., 6] & 0xFFFF).sum()) == cnt["extend_rays"] and int((dbg[..., 6] >> 16).sum()) == cnt["shadow_rays"]
+    assert int(dbg[..., 7].astype(np.uint64).sum()) == cnt["index_loads"]
+    # sharded render is bit-identical to the unsharded one at full size
+    out = np.zeros_like(acc)
+    for r in range(2):
+        a, _ = gpu_render(bm, torch, scene, cam, bm.FrameParams(W, H, spp=1, max_bounces=3, band_rows=16, shard_rank=r, shard_count=2), want_dbg=False)
+        out[bm.dist.shard_rows(H, 16, r, 2)] = a
+    assert np.array_equal(out, acc)
+    # oracle on a 1/60 sample of the rows
+    w = orc.World(G, G)
+    w.reset_device(True)
+    oacc, odbg, _, _ = w.render(ocam, orc.make_frame(W, H, spp=1, max_bounces=3, band_rows=1, shard_rank=7, shard_count=60),
+                                threads=os.cpu_count() or 1)
+    rows = bm.dist.shard_rows(H, 1, 7, 60)
+    assert np.array_equal(dbg[rows], odbg[rows])
+    assert_radiance(acc[rows], oacc[rows])
+    scene.close()
+
+
+def test_errors_are_reported_not_fatal(bm, torch_cuda):
+    import ctypes as C
+    from brickmap_amd import _lib
+    L = _lib.load()
+    h = C.c_void_p()
+    assert L.bm_scene_create(0, 100, 128, C.byref(h)) == 10001 and b"multiples of 128" in L.bm_last_error_string()
+    s = bm.Scene(128, 128, device=0)
+    with pytest.raises(bm.BrickmapError):
+        s.preload_all()  # not generated yet
+    s.close()

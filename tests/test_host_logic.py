@@ -1,0 +1,89 @@
+"""Host-side logic of the product (no GPU): the C-ABI loads and exports every declared symbol,
+row sharding, the CPU world builder against the oracle, and the layering rules."""
+import os
+import re
+
+import numpy as np
+
+from conftest import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "brickmap.h")).read()
+    return sorted(set(re.findall(r"BM_API\s+[\w\s\*]+?\b(bm_\w+)\s*\(", text)))
+
+
+def test_cabi_exports_every_declared_symbol(bm):
+    import ctypes as C
+    from brickmap_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 30
+    L = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), f"{n} is declared in include/brickmap.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "python bindings and header disagree"
+
+
+def test_error_reporting_without_gpu(bm):
+    from brickmap_amd import _lib
+    L = _lib.load()
+    assert L.bm_scene_get_info(None, None) == 10001  # BM_EINVAL, message set, no abort
+    assert b"null scene" in L.bm_last_error_string()
+    import ctypes as C
+    out = np.zeros((128, 128), np.float32)
+    assert L.bm_host_column_heights(100, 128, 0, 0, out.ctypes.data) == 10001  # not a multiple of 128
+
+
+def test_local_rows_matches_shard_rows(bm):
+    for H in (1, 15, 16, 17, 70, 1080, 2160):
+        for band in (1, 7, 16, 32):
+            for world in (1, 2, 3, 8):
+                owned = [bm.dist.shard_rows(H, band, r, world) for r in range(world)]
+                assert sorted(np.concatenate(owned).tolist()) == list(range(H))
+                for r in range(world):
+                    got = bm.local_rows(bm.FrameParams(64, H, band_rows=band, shard_rank=r, shard_count=world))
+                    assert got == len(owned[r])
+
+
+def test_camera_update_matches_oracle(bm, orc):
+    for h, v in [(0.8, -0.5), (0.0, 0.0), (-3.1, 1.2), (10.0, -1.5)]:
+        cam = bm.Camera(horizontal_angle=h, vertical_angle=v).update()
+        assert np.array_equal(np.float32(cam.direction), orc.camera_direction(h, v))
+    c = bm.Camera()
+    assert c.position == (512.0, 512.0, 300.0) and c.up == (0.0, 0.0, 1.0) and c.focalDistance == 1.0 and c.lensRadius == 0.0
+
+
+def test_world_builder_matches_oracle(bm, orc):
+    """brickmap_amd/csrc/world.cpp (product) against oracle.c (checker): bit-identical heights,
+    index words and bricks, on a cubic and on a non-cubic world."""
+    for (gs, gh) in [(256, 256), (384, 128)]:
+        w = orc.World(gs, gh)
+        sxy, sz_n = gs // 128, gh // 128
+        for sz in range(sz_n):
+            for sy in range(sxy):
+                for sx in range(sxy):
+                    sc = sx + sy * sxy + sz * sxy * sxy
+                    idx, bricks = bm.host_generate_supercell(gs, gh, sx, sy, sz)
+                    assert np.array_equal(idx, w.sc_indices(sc))
+                    assert np.array_equal(bricks, w.sc_bricks(sc))
+        h = bm.host_column_heights(gs, gh, sxy - 1, 0)
+        assert np.array_equal(h.view(np.uint32), w.column_heights(sxy - 1, 0).view(np.uint32))
+
+
+def test_product_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use oracle/."""
+    pkg = os.path.join(ROOT, "brickmap_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in text and "from oracle" not in text and "liboracle" not in text, f
+                assert "oracle/" not in text.replace("oracle/oracle.c orc_counters", ""), f
+    inc = open(os.path.join(ROOT, "include", "brickmap.h")).read()
+    assert "liboracle" not in inc
+
+
+def test_no_reference_reads_at_runtime():
+    """/root/reference does not exist on the GPU box: product, bench and smoke never open it."""
+    for rel in ["bench.py", "__graft_entry__.py", "brickmap_amd/_lib.py", "brickmap_amd/host.py", "brickmap_amd/dist.py"]:
+        assert "/root/reference" not in open(os.path.join(ROOT, rel)).read(), rel
