@@ -10,13 +10,28 @@ namespace bm {
 //   index_grid  u32[supercells * 4096]   supercell-major; supercell id = sx + sy*sg_xy + sz*sg_xy^2,
 //                                         word (lx + 16*ly + 256*lz) inside it  -- the reference's
 //                                         addressing (voxel.cuh:197-198) minus its pointer table
-//   brick_base  u32[supercells]          first arena slot of each supercell (exclusive prefix sum of
-//                                         its non-empty brick count) -- replaces the Brick** table
-//   brick_arena 64 B * total_bricks      exact-fit pool; slot = brick_base[sc] + (word & 0xFFF)
+//   super_info  16 B per supercell        {u64 coarse occupancy, u32 brick_base, u32 0}: bit
+//                                         (bx + 4*by + 16*bz) of `coarse` says whether the 4x4x4-brick
+//                                         block (bx,by,bz) of the supercell holds any non-empty brick;
+//                                         brick_base = first arena slot of the supercell (exclusive
+//                                         prefix sum of non-empty brick counts; replaces Brick**)
+//   fine_mask   u64[supercells * 64]      per 4x4x4-brick block: bit (cx + 4*cy + 16*cz) = "index word
+//                                         of that brick is non-zero".  Static (residency flags never make
+//                                         a word zero), so the DDA can skip the index load of empty cells
+//                                         while still performing the reference's per-cell arithmetic.
+//   brick_arena 64 B * total_bricks      exact-fit pool; slot = brick_base + (word & 0xFFF)
 //   load_queue  int3[queue_cap] + count  brick-request ring (voxel.cuh:228-245)
+struct SuperInfo {
+	unsigned long long coarse;
+	uint32_t brick_base;
+	uint32_t reserved;
+};
+static_assert(sizeof(SuperInfo) == 16, "one dwordx4 per supercell");
+
 struct DeviceScene {
 	uint32_t* index_grid;
-	const uint32_t* brick_base;
+	const SuperInfo* super_info;
+	const unsigned long long* fine_mask;
 	const uint32_t* brick_arena; // 16 words per brick
 	int* load_queue;             // 3 ints per entry
 	uint32_t* load_queue_count;

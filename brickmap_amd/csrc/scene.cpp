@@ -184,9 +184,12 @@ int Scene::set_queue_capacity(int cap) {
 
 void Scene::free_device() {
 	if (d_index_grid_) hipFree(d_index_grid_);
-	if (d_brick_base_) hipFree(d_brick_base_);
+	if (d_super_info_) hipFree(d_super_info_);
+	if (d_fine_mask_) hipFree(d_fine_mask_);
 	if (d_arena_) hipFree(d_arena_);
-	d_index_grid_ = d_brick_base_ = d_arena_ = nullptr;
+	d_index_grid_ = d_arena_ = nullptr;
+	d_super_info_ = nullptr;
+	d_fine_mask_ = nullptr;
 	on_device_ = false;
 }
 
@@ -206,11 +209,22 @@ int Scene::allocate_device() {
 	total_bricks_ = run;
 	const size_t index_bytes = static_cast<size_t>(d.supercells) * kCellsPerSupercell * sizeof(uint32_t);
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_index_grid_), index_bytes));
-	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_brick_base_), static_cast<size_t>(d.supercells) * sizeof(uint32_t)));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_super_info_), static_cast<size_t>(d.supercells) * sizeof(SuperInfo)));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_fine_mask_), static_cast<size_t>(d.supercells) * 64 * sizeof(unsigned long long)));
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_arena_), std::max<size_t>(64, static_cast<size_t>(total_bricks_) * sizeof(Brick))));
-	BM_HIP(hipMemcpy(d_brick_base_, brick_base_.data(), brick_base_.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	{
+		std::vector<SuperInfo> info(d.supercells);
+		std::vector<unsigned long long> fine(static_cast<size_t>(d.supercells) * 64);
+		for (int i = 0; i < d.supercells; ++i) {
+			info[i] = SuperInfo{world.supercells[i].coarse_mask, brick_base_[i], 0u};
+			for (int b = 0; b < 64; ++b) fine[static_cast<size_t>(i) * 64 + b] = world.supercells[i].fine_mask[b];
+		}
+		BM_HIP(hipMemcpy(d_super_info_, info.data(), info.size() * sizeof(SuperInfo), hipMemcpyHostToDevice));
+		BM_HIP(hipMemcpy(d_fine_mask_, fine.data(), fine.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+	}
 	view_.index_grid = d_index_grid_;
-	view_.brick_base = d_brick_base_;
+	view_.super_info = d_super_info_;
+	view_.fine_mask = d_fine_mask_;
 	view_.brick_arena = d_arena_;
 	view_.cells = d.cells;
 	view_.cells_height = d.cells_height;

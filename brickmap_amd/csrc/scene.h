@@ -70,7 +70,8 @@ private:
 
 	// device memory (DeviceScene view)
 	uint32_t* d_index_grid_ = nullptr;
-	uint32_t* d_brick_base_ = nullptr;
+	SuperInfo* d_super_info_ = nullptr;
+	unsigned long long* d_fine_mask_ = nullptr;
 	uint32_t* d_arena_ = nullptr;
 	int* d_load_queue_ = nullptr;
 	uint32_t* d_load_count_ = nullptr;

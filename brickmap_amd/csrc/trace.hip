@@ -23,7 +23,6 @@ namespace {
 
 constexpr float kPi = 3.1415926535897932f;       // variables.h:3
 constexpr float kEpsilon = 0.001f;               // variables.h:22
-constexpr float kVeryFar = 1e20f;                // kernel.cu:12
 constexpr uint32_t kIndexBits = 0xFFFu;          // variables.h:29-33
 constexpr uint32_t kLodBits = 0xFF000u;
 constexpr uint32_t kLoadedBit = 0x80000000u;
@@ -117,18 +116,64 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, f3& normal, fl
 	return false;
 }
 
-// ---- brick-grid DDA (voxel.cuh:135-261)
+// ---- brick-grid DDA (voxel.cuh:135-261), split into the three pieces the wave scheduler interleaves
+//
+// The reference reads one 32-bit index word per visited cell (two dependent loads through its pointer
+// table).  ~96 % of those words are zero (air), so the walk consults a two-level occupancy summary kept
+// in registers -- a 64-bit mask of the current 4x4x4-brick block and a 64-bit mask of the current
+// supercell's blocks (DeviceScene) -- and touches the index grid only at cells known to be non-empty.
+// Masks are re-read only when the walk crosses a block / supercell boundary, and because the world edge
+// is a supercell boundary the reference's per-step exit test (voxel.cuh:256) moves into that rare path too.
+// The per-cell arithmetic (axis choice, tmax accumulation) is the reference's, step for step.
+struct RayState {
+	f3 o, d;            // origin (brick units once set up) and direction
+	float tx, ty, tz;   // tmax
+	float dx, dy, dz;   // tdelta = |1/d|
+	int px, py, pz;     // current brick cell
+	int sx, sy, sz;     // step signs
+	float tminn;
+	f3 n;               // normal carried in/out of the traversal (voxel.cuh:135 `normal`)
+	int axis;           // axis of the last move, -1 before the first
+	unsigned long long coarse, fine;
+	uint32_t brick_base;
+	int sci;
+	int guard;
+	float distance;     // result
+	bool hit;
+};
+
+enum : int { ST_NEED = 0, ST_OUTER = 1, ST_CAND = 2, ST_FIN = 3 };
+
+__device__ __forceinline__ void load_super(const DeviceScene& sc, RayState& r) {
+	r.sci = (r.px >> 4) + (r.py >> 4) * sc.sg_xy + (r.pz >> 4) * sc.sg_xy2;
+	const uint4 rec = *reinterpret_cast<const uint4*>(sc.super_info + r.sci);
+	r.coarse = static_cast<unsigned long long>(rec.x) | (static_cast<unsigned long long>(rec.y) << 32);
+	r.brick_base = rec.z;
+}
+__device__ __forceinline__ void load_block(const DeviceScene& sc, RayState& r) {
+	const int bi = ((r.px >> 2) & 3) + (((r.py >> 2) & 3) << 2) + (((r.pz >> 2) & 3) << 4);
+	r.fine = 0ull;
+	if ((r.coarse >> bi) & 1ull) r.fine = sc.fine_mask[(static_cast<size_t>(r.sci) << 6) + bi];
+}
+__device__ __forceinline__ bool cell_occupied(const RayState& r) {
+	const int ci = (r.px & 3) + ((r.py & 3) << 2) + ((r.pz & 3) << 4);
+	return (r.fine >> ci) & 1ull;
+}
+
+// voxel.cuh:136-189: clip against the world box, move onto it, set up the Amanatides-Woo state.
+// Returns the lane's next state: ST_OUTER / ST_CAND, or ST_NEED with r.hit = false when the ray misses the box.
 template <bool DBG>
-__device__ __forceinline__ bool intersect_voxel(const DeviceScene& sc, const int campos_x, const int campos_y, const int campos_z, f3 origin,
-												const f3 dir, f3& normal, float& distance, HitInfo& info, Tally& tally) {
+__device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const f3 dir, RayState& r, Tally& tally) {
+	r.hit = false;
+	r.d = dir;
 	// intersect_aabb_branchless2 (voxel.cuh:13-24)
 	const f3 t1 = (mk(0.f, 0.f, 0.f) - origin) / dir;
 	const f3 t2 = (mk(sc.grid_size_f, sc.grid_size_f, sc.grid_height_f) - origin) / dir;
 	const f3 tMin = mk(gmin(t1.x, t2.x), gmin(t1.y, t2.y), gmin(t1.z, t2.z));
 	const f3 tMax = mk(gmax(t1.x, t2.x), gmax(t1.y, t2.y), gmax(t1.z, t2.z));
 	const float tminn = gmax(gmax(tMin.x, 0.f), gmax(tMin.y, tMin.z));
-	if (!(gmin(tMax.x, gmin(tMax.y, tMax.z)) > tminn)) return false;
-
+	if (!(gmin(tMax.x, gmin(tMax.y, tMax.z)) > tminn)) return ST_NEED;
+	r.tminn = tminn;
 	if (tminn > 0) { // move the ray onto the box and derive the entry-face normal (voxel.cuh:142-155)
 		origin = origin + dir * tminn;
 		const float gs = sc.grid_size_f, gh = sc.grid_height_f;
@@ -139,98 +184,133 @@ __device__ __forceinline__ bool intersect_voxel(const DeviceScene& sc, const int
 		const f3 e = origin - center;
 		const f3 signs = mk(static_cast<float>(isign(e.x)), static_cast<float>(isign(e.y)), static_cast<float>(isign(e.z)));
 		to_center = to_center / gmax(to_center.x, gmax(to_center.y, to_center.z));
-		normal = signs * mk(truncf(to_center.x + 0.000001f), truncf(to_center.y + 0.000001f), truncf(to_center.z + 0.000001f));
-		origin = origin - normal * kEpsilon;
+		r.n = signs * mk(truncf(to_center.x + 0.000001f), truncf(to_center.y + 0.000001f), truncf(to_center.z + 0.000001f));
+		origin = origin - r.n * kEpsilon;
 	}
 	origin = origin / 8.f;
-	int px = static_cast<int>(origin.x), py = static_cast<int>(origin.y), pz = static_cast<int>(origin.z);
+	r.o = origin;
+	r.px = static_cast<int>(origin.x); r.py = static_cast<int>(origin.y); r.pz = static_cast<int>(origin.z);
 	const int cells = sc.cells, cells_h = sc.cells_height;
-	if (px < 0 || px >= cells || py < 0 || py >= cells || pz < 0 || pz >= cells_h) return false;
-
-	const float cbx = dir.x > 0.f ? static_cast<float>(px + 1) : static_cast<float>(px);
-	const float cby = dir.y > 0.f ? static_cast<float>(py + 1) : static_cast<float>(py);
-	const float cbz = dir.z > 0.f ? static_cast<float>(pz + 1) : static_cast<float>(pz);
-	const int outx = dir.x > 0.f ? cells : -1, outy = dir.y > 0.f ? cells : -1, outz = dir.z > 0.f ? cells_h : -1;
-	const int sx = isign(dir.x), sy = isign(dir.y), sz = isign(dir.z);
+	if (r.px < 0 || r.px >= cells || r.py < 0 || r.py >= cells || r.pz < 0 || r.pz >= cells_h) return ST_NEED;
+	const float cbx = dir.x > 0.f ? static_cast<float>(r.px + 1) : static_cast<float>(r.px);
+	const float cby = dir.y > 0.f ? static_cast<float>(r.py + 1) : static_cast<float>(r.py);
+	const float cbz = dir.z > 0.f ? static_cast<float>(r.pz + 1) : static_cast<float>(r.pz);
+	r.sx = isign(dir.x); r.sy = isign(dir.y); r.sz = isign(dir.z);
 	const float rx = dir.x == 0.0f ? 0.0f : 1.f / dir.x;
 	const float ry = dir.y == 0.0f ? 0.0f : 1.f / dir.y;
 	const float rz = dir.z == 0.0f ? 0.0f : 1.f / dir.z;
-	float tx = dir.x != 0.f ? (cbx - origin.x) * rx : 1000000.f;
-	float ty = dir.y != 0.f ? (cby - origin.y) * ry : 1000000.f;
-	float tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
-	const float dx = static_cast<float>(sx) * rx, dy = static_cast<float>(sy) * ry, dz = static_cast<float>(sz) * rz;
-
-	int axis = -1;
+	r.tx = dir.x != 0.f ? (cbx - origin.x) * rx : 1000000.f;
+	r.ty = dir.y != 0.f ? (cby - origin.y) * ry : 1000000.f;
+	r.tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
+	r.dx = static_cast<float>(r.sx) * rx; r.dy = static_cast<float>(r.sy) * ry; r.dz = static_cast<float>(r.sz) * rz;
+	r.axis = -1;
 	// a well-formed ray makes at most 2*cells + cells_h steps; the bound only protects the GPU from NaN input
-	int guard = 4 * (2 * cells + cells_h) + 16;
-	while (guard-- > 0) {
-		// inside the loop 0 <= pos < cells, so >>4 and &15 equal the reference's signed /16 and %16
-		const int sci = (px >> 4) + (py >> 4) * sc.sg_xy + (pz >> 4) * sc.sg_xy2;
-		const uint32_t flat = (static_cast<uint32_t>(sci) << 12) + static_cast<uint32_t>((px & 15) + ((py & 15) << 4) + ((pz & 15) << 8));
-		const uint32_t index = sc.index_grid[flat];
-		if (DBG) tally.index_loads++;
-		if (index) {
-			float new_distance = 0.f;
-			if (axis != -1) {
-				normal = mk(0.f, 0.f, 0.f);
-				if (axis == 0) { normal.x = -static_cast<float>(sx); new_distance = tx - dx; }
-				else if (axis == 1) { normal.y = -static_cast<float>(sy); new_distance = ty - dy; }
-				else { normal.z = -static_cast<float>(sz); new_distance = tz - dz; }
-			}
-			const int ddx = campos_x - px, ddy = campos_y - py, ddz = campos_z - pz;
-			const int lod2 = ddx * ddx + ddy * ddy + ddz * ddz;
-			float sub_distance = 0.f;
-			if (DBG) info.brick_id = px + py * cells + pz * cells * cells;
-			if (lod2 > sc.lod_distance_8x8x8) {
-				distance = new_distance * 8.f + tminn;
-				if (DBG) { info.level = 0; info.sub_id = 0; }
-				return true;
-			} else if (lod2 > sc.lod_distance_2x2x2) {
-				if (DBG) tally.byte_tests++;
-				int sub = 0;
-				const f3 o2 = (origin + dir * new_distance) * 2.f - normal * 0.2f * kEpsilon;
-				if (intersect_grid<2, DBG>(o2, dir, normal, sub_distance, nullptr, (index & kLodBits) >> 12, sub, tally)) {
-					distance = new_distance * 8.f + sub_distance * 4.f + tminn;
-					if (DBG) { info.level = 1; info.sub_id = sub; }
-					return true;
-				}
-			} else if (index & kLoadedBit) {
-				if (DBG) tally.brick_tests++;
-				int sub = 0;
-				const uint32_t slot = sc.brick_base[sci] + (index & kIndexBits);
-				const uint32_t* brick = sc.brick_arena + (static_cast<size_t>(slot) << 4);
-				const f3 o8 = (origin + dir * new_distance) * 8.f - normal * kEpsilon;
-				if (intersect_grid<8, DBG>(o8, dir, normal, sub_distance, brick, 0u, sub, tally)) {
-					distance = new_distance * 8.f + sub_distance + tminn;
-					if (DBG) { info.level = 2; info.sub_id = sub; }
-					return true;
-				}
-			} else if (index & kUnloadedBit) {
-				// brick-request protocol (voxel.cuh:228-245): 32-bit atomics on the index word and the ring counter
-				const uint32_t old = atomicOr(&sc.index_grid[flat], kRequestedBit);
-				if (!(old & kRequestedBit)) {
-					const uint32_t load_index = atomicAdd(sc.load_queue_count, 1u);
-					if (load_index < sc.queue_cap) {
-						int* q = sc.load_queue + 3 * static_cast<size_t>(load_index);
-						q[0] = px; q[1] = py; q[2] = pz;
-						if (DBG) tally.requests++;
-					} else {
-						atomicAnd(&sc.index_grid[flat], ~kRequestedBit);
-					}
-				}
-				distance = new_distance * 8.f + tminn;
-				if (DBG) { info.level = 3; info.sub_id = 0; }
-				return true;
+	r.guard = 4 * (2 * cells + cells_h) + 16;
+	load_super(sc, r);
+	load_block(sc, r);
+	if (DBG) tally.index_loads++; // one per visited cell = the reference's index loads (algorithmic count)
+	return cell_occupied(r) ? ST_CAND : ST_OUTER;
+}
+
+// voxel.cuh:249-258: one Amanatides-Woo move to the next cell.  Returns the next state.
+template <bool DBG>
+__device__ __forceinline__ int outer_step(const DeviceScene& sc, RayState& r, Tally& tally) {
+	const bool mx = r.tx < r.ty && r.tx < r.tz;
+	const bool my = !mx && r.ty <= r.tx && r.ty < r.tz;
+	bool reload_super = false, reload_block = false, left = false;
+	// a move along -axis crosses a 4- / 16-aligned boundary when the NEW coordinate + 1 is aligned
+	if (mx) {
+		r.axis = 0;
+		r.px += r.sx;
+		const int c = r.px + (r.sx < 0 ? 1 : 0);
+		if ((c & 3) == 0) { reload_block = true; if ((c & 15) == 0) { left = r.px == (r.sx > 0 ? sc.cells : -1); reload_super = true; } }
+		r.tx += r.dx;
+	} else if (my) {
+		r.axis = 1;
+		r.py += r.sy;
+		const int c = r.py + (r.sy < 0 ? 1 : 0);
+		if ((c & 3) == 0) { reload_block = true; if ((c & 15) == 0) { left = r.py == (r.sy > 0 ? sc.cells : -1); reload_super = true; } }
+		r.ty += r.dy;
+	} else {
+		r.axis = 2;
+		r.pz += r.sz;
+		const int c = r.pz + (r.sz < 0 ? 1 : 0);
+		if ((c & 3) == 0) { reload_block = true; if ((c & 15) == 0) { left = r.pz == (r.sz > 0 ? sc.cells_height : -1); reload_super = true; } }
+		r.tz += r.dz;
+	}
+	if (left || --r.guard <= 0) return ST_NEED; // left the grid: the ray missed (r.hit stays false)
+	if (reload_block) {
+		if (reload_super) load_super(sc, r);
+		load_block(sc, r);
+	}
+	if (DBG) tally.index_loads++;
+	return cell_occupied(r) ? ST_CAND : ST_OUTER;
+}
+
+// voxel.cuh:200-247: the current cell holds a non-empty brick -- read its index word and resolve it.
+template <bool DBG>
+__device__ __forceinline__ int process_candidate(const DeviceScene& sc, const int* campos, RayState& r, HitInfo& info, Tally& tally) {
+	const int px = r.px, py = r.py, pz = r.pz;
+	// inside the grid 0 <= pos < cells, so >>4 and &15 equal the reference's signed /16 and %16
+	const uint32_t flat = (static_cast<uint32_t>(r.sci) << 12) + static_cast<uint32_t>((px & 15) + ((py & 15) << 4) + ((pz & 15) << 8));
+	const uint32_t index = sc.index_grid[flat];
+	float new_distance = 0.f;
+	if (r.axis != -1) {
+		r.n = mk(0.f, 0.f, 0.f);
+		if (r.axis == 0) { r.n.x = -static_cast<float>(r.sx); new_distance = r.tx - r.dx; }
+		else if (r.axis == 1) { r.n.y = -static_cast<float>(r.sy); new_distance = r.ty - r.dy; }
+		else { r.n.z = -static_cast<float>(r.sz); new_distance = r.tz - r.dz; }
+	}
+	const int ddx = campos[0] - px, ddy = campos[1] - py, ddz = campos[2] - pz;
+	const int lod2 = ddx * ddx + ddy * ddy + ddz * ddz;
+	float sub_distance = 0.f;
+	if (DBG) info.brick_id = px + py * sc.cells + pz * sc.cells * sc.cells;
+	if (lod2 > sc.lod_distance_8x8x8) {
+		r.distance = new_distance * 8.f + r.tminn;
+		if (DBG) { info.level = 0; info.sub_id = 0; }
+		r.hit = true;
+		return ST_NEED;
+	} else if (lod2 > sc.lod_distance_2x2x2) {
+		if (DBG) tally.byte_tests++;
+		int sub = 0;
+		const f3 o2 = (r.o + r.d * new_distance) * 2.f - r.n * 0.2f * kEpsilon;
+		if (intersect_grid<2, DBG>(o2, r.d, r.n, sub_distance, nullptr, (index & kLodBits) >> 12, sub, tally)) {
+			r.distance = new_distance * 8.f + sub_distance * 4.f + r.tminn;
+			if (DBG) { info.level = 1; info.sub_id = sub; }
+			r.hit = true;
+			return ST_NEED;
+		}
+	} else if (index & kLoadedBit) {
+		if (DBG) tally.brick_tests++;
+		int sub = 0;
+		const uint32_t slot = r.brick_base + (index & kIndexBits);
+		const uint32_t* brick = sc.brick_arena + (static_cast<size_t>(slot) << 4);
+		const f3 o8 = (r.o + r.d * new_distance) * 8.f - r.n * kEpsilon;
+		if (intersect_grid<8, DBG>(o8, r.d, r.n, sub_distance, brick, 0u, sub, tally)) {
+			r.distance = new_distance * 8.f + sub_distance + r.tminn;
+			if (DBG) { info.level = 2; info.sub_id = sub; }
+			r.hit = true;
+			return ST_NEED;
+		}
+	} else if (index & kUnloadedBit) {
+		// brick-request protocol (voxel.cuh:228-245): 32-bit atomics on the index word and the ring counter
+		const uint32_t old = atomicOr(&sc.index_grid[flat], kRequestedBit);
+		if (!(old & kRequestedBit)) {
+			const uint32_t load_index = atomicAdd(sc.load_queue_count, 1u);
+			if (load_index < sc.queue_cap) {
+				int* q = sc.load_queue + 3 * static_cast<size_t>(load_index);
+				q[0] = px; q[1] = py; q[2] = pz;
+				if (DBG) tally.requests++;
+			} else {
+				atomicAnd(&sc.index_grid[flat], ~kRequestedBit);
 			}
 		}
-		const bool mx = tx < ty && tx < tz;
-		const bool my = !mx && ty <= tx && ty < tz;
-		axis = (tx < ty) ? ((tx < tz) ? 0 : 2) : ((ty < tz) ? 1 : 2);
-		if (mx) { px += sx; if (px == outx) break; tx += dx; }
-		else if (my) { py += sy; if (py == outy) break; ty += dy; }
-		else { pz += sz; if (pz == outz) break; tz += dz; }
+		r.distance = new_distance * 8.f + r.tminn;
+		if (DBG) { info.level = 3; info.sub_id = 0; }
+		r.hit = true;
+		return ST_NEED;
 	}
-	return false;
+	return ST_OUTER; // nothing solid along the ray inside this brick: keep walking
 }
 
 // ---- sky model (sunsky.cu:10-161); view-independent terms arrive precomputed in FrameConstants
@@ -323,6 +403,17 @@ __device__ __forceinline__ uint32_t pack_normal(f3 n) {
 
 } // namespace
 
+// Path state machine.  Each lane owns one pixel and walks through
+//   GEN -> [extend ray] -> EXT_DONE (shade) -> [shadow ray] -> SHD_DONE (connect) -> BOUNCE -> [extend ray] ...
+// A 64-lane wave interleaves three kinds of work, each run only when enough lanes want it (or nothing
+// else can run), so that the expensive, rarely-needed code never executes for a handful of lanes:
+//   phase A  one brick-grid DDA move            lanes in ST_OUTER   (cheap, most of the work)
+//   phase B  index word + 8^3 / 2^3 bitmask DDA  lanes in ST_CAND    (expensive, ~2.5 per ray)
+//   phase C  shade / connect / next ray + setup  lanes in ST_NEED    (expensive, once per ray)
+// Scheduling changes only WHEN a lane's operations happen, never their operands, so results are
+// identical to the reference's per-ray functions run one ray at a time (the oracle).
+enum : int { P_GEN = 0, P_EXT_DONE = 1, P_SHD_DONE = 2, P_BOUNCE = 3 };
+
 template <bool DBG>
 __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const FrameConstants fc, float4* __restrict__ accum,
 												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters) {
@@ -336,7 +427,7 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 	const int x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
 	const int ly = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3); // row inside this shard's packed buffer
 	const int y = ((ly / fc.band_rows) * fc.shard_count + fc.shard_rank) * fc.band_rows + ly % fc.band_rows;
-	// lanes outside the image stay alive (they only skip the work) so that wave-wide reductions below are well defined
+	// lanes outside the image stay alive (they only skip the work) so that wave-wide votes are well defined
 	const bool valid = x < fc.width && ly < fc.local_rows && y < fc.height;
 
 	const uint32_t W = static_cast<uint32_t>(fc.width), H = static_cast<uint32_t>(fc.height);
@@ -344,135 +435,190 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 	const size_t local_pixel = static_cast<size_t>(ly) * W + static_cast<size_t>(x);
 	float4 acc = valid ? accum[local_pixel] : make_float4(0.f, 0.f, 0.f, 0.f);
 
-	const f3 cam_right = ld3(fc.right), cam_up = ld3(fc.up), cam_dir = ld3(fc.dir), cam_o = ld3(fc.origin);
-	const f3 sunDir = ld3(fc.sun_direction);
 	Tally tally;
+	HitInfo info;
 	uint32_t d0 = 0, d1 = 0, d2 = 0xFFFFFFFFu, d3 = 0, hseg = 2166136261u, hsh = 2166136261u, next = 0, nsh = 0;
 
-	const int spp = valid ? fc.spp : 0;
-	for (int s = 0; s < spp; ++s) {
-		const uint32_t slot = p + static_cast<uint32_t>(fc.sample_base + s) * W * H;
-		// ---- primary_rays (kernel.cu:157-200) for queue slot `slot`, start_position 0
-		uint32_t seed = (fc.base_frame * 147565741u) * 720898027u * slot;
-		f3 origin, direction;
-		{
-			// Random2DStratifiedSample (kernel.cu:40-61)
-			const int stratum = static_cast<int>(random_float(seed) * (16 + 0.99999f));
-			const int stratumX = stratum % 4, stratumY = (stratum / 4) % 4;
-			const float sx = 0.25f * stratumX + (random_float(seed) * 0.25f);
-			const float sy = 0.25f * stratumY + (random_float(seed) * 0.25f);
-			const float ppx = static_cast<float>(static_cast<uint32_t>(x)) - sx;
-			const float ppy = static_cast<float>(static_cast<uint32_t>(y)) - sy;
-			const float ni = (ppx / static_cast<float>(W)) - 0.5f;
-			const float nj = ((static_cast<float>(H) - ppy) / static_cast<float>(H)) - 0.5f;
-			const f3 to_focal = normalize(cam_dir + cam_right * ni + cam_up * nj);
-			const f3 convergence = cam_o + to_focal * fc.focal3;
-			const float l0 = random_float(seed); // canonical order: left to right
-			const float l1 = random_float(seed);
-			float lx = 0.f, lyy = 0.f;
-			{ // ConcentricSampleDisk (kernel.cu:85-103)
-				const float ox = 2.f * l0 - 1.f, oy = 2.f * l1 - 1.f;
-				if (!(ox == 0 && oy == 0)) {
-					float theta, r;
-					if (fabsf(ox) > fabsf(oy)) { r = ox; theta = kPi / 4 * (oy / ox); }
-					else { r = oy; theta = kPi / 2 - kPi / 4 * (ox / oy); }
-					float sn, cs;
-					det_sincos(theta, sn, cs);
-					lx = r * cs;
-					lyy = r * sn;
-				}
-			}
-			const float plx = fc.lens_radius * lx, ply = fc.lens_radius * lyy;
-			origin = cam_o + cam_right * plx + cam_up * ply;
-			direction = normalize(convergence - origin);
-		}
-		f3 throughput = mk(1.f, 1.f, 1.f), normal = mk(0.f, 0.f, 0.f);
-		int bounces = 0;
-		if (DBG) tally.paths++;
+	RayState r;
+	r.hit = false;
+	r.n = mk(0.f, 0.f, 0.f);
+	int state = valid ? ST_NEED : ST_FIN;
+	int pstate = P_GEN;
+	int s = 0;               // sample being traced
+	int bounces = 0;
+	bool shadow = false;     // kind of the ray in flight
+	bool terminated = false; // path ends after its pending shadow ray
+	uint32_t slot = 0, sseed = 0;
+	f3 hitp = mk(0.f, 0.f, 0.f);   // surface point: shadow-ray origin and next extend origin
+	f3 pn = mk(0.f, 0.f, 0.f);     // surface normal of the path (RayQueue::normal)
+	f3 pdir = mk(0.f, 0.f, 0.f);   // direction of the extend ray in flight (RayQueue::direction)
+	f3 scolor = mk(0.f, 0.f, 0.f); // ShadowQueue::color
 
-		for (;;) {
-			// ---- extend (kernel.cu:226-238)
-			float distance = kVeryFar;
-			HitInfo info;
-			intersect_voxel<DBG>(sc, fc.campos[0], fc.campos[1], fc.campos[2], origin, direction, normal, distance, info, tally);
-			const bool is_hit = distance < kVeryFar;
-			if (DBG) {
-				tally.extend_rays++;
-				next++;
-				if (s == 0 && bounces == 0) {
-					d0 = is_hit ? __float_as_uint(distance) : 0u;
-					d1 = is_hit ? (pack_normal(normal) | (1u << 8) | (static_cast<uint32_t>(info.level) << 12)) : 0u;
-					d2 = is_hit ? static_cast<uint32_t>(info.brick_id) : 0xFFFFFFFFu;
-					d3 = is_hit ? static_cast<uint32_t>(info.sub_id) : 0u;
+	for (;;) {
+		const int nA = __popcll(__ballot(state == ST_OUTER));
+		const int nB = __popcll(__ballot(state == ST_CAND));
+		const int nC = __popcll(__ballot(state == ST_NEED));
+		const int live = nA + nB + nC;
+		if (live == 0) break;
+		const int quorum = (live + 2) / 3;
+
+		if (nC >= quorum || (nA == 0 && nB == 0)) {
+			// ================= phase C: path logic for lanes whose ray just finished (or that need their first ray)
+			if (state == ST_NEED) {
+				bool need_setup = false;
+				f3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f);
+				if (pstate == P_EXT_DONE) {
+					// ---- extend finished (kernel.cu:226-238); `hit <=> distance < VERY_FAR`
+					const bool is_hit = r.hit;
+					pn = r.n; // extend writes RayQueue::normal in place (also clobbered on the way to a miss; unused then)
+					if (DBG) {
+						tally.extend_rays++;
+						next++;
+						if (s == 0 && bounces == 0) {
+							d0 = is_hit ? __float_as_uint(r.distance) : 0u;
+							d1 = is_hit ? (pack_normal(pn) | (1u << 8) | (static_cast<uint32_t>(info.level) << 12)) : 0u;
+							d2 = is_hit ? static_cast<uint32_t>(info.brick_id) : 0xFFFFFFFFu;
+							d3 = is_hit ? static_cast<uint32_t>(info.sub_id) : 0u;
+						}
+						hseg = hmix(hseg, static_cast<uint32_t>(is_hit));
+						if (is_hit) {
+							hseg = hmix(hseg, __float_as_uint(r.distance));
+							hseg = hmix(hseg, pack_normal(pn) | (static_cast<uint32_t>(info.level) << 12));
+							hseg = hmix(hseg, static_cast<uint32_t>(info.brick_id));
+							hseg = hmix(hseg, static_cast<uint32_t>(info.sub_id));
+						}
+					}
+					if (fc.flags & 1u) { // BM_FLAG_PRIMARY_ONLY
+						if (!is_hit) {
+							const f3 c = sunsky_radiance(fc, pdir);
+							acc.x += c.x; acc.y += c.y; acc.z += c.z;
+						}
+						acc.w += 1.f;
+						s++;
+						pstate = P_GEN;
+					} else if (!is_hit) {
+						// ---- shade, miss branch (kernel.cu:316-323); throughput is identically (1,1,1) (kernel.cu:261,271)
+						const f3 c = bounces == 0 ? sunsky_radiance(fc, pdir) : sky_radiance(fc, pdir);
+						acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.f;
+						s++;
+						pstate = P_GEN;
+					} else {
+						// ---- shade, hit branch (kernel.cu:255-302); frame = base_frame + bounce, queue slot = slot
+						const uint32_t frame = fc.base_frame + static_cast<uint32_t>(bounces);
+						sseed = (frame * p * 147565741u) * 720898027u * slot;
+						hitp = hitp + pdir * r.distance;
+						hitp = hitp + pn * 2.f * kEpsilon;
+						const f3 sunSampleDir = cone_sample(ld3(fc.sun_direction), fc.cone_extent, sseed);
+						const float sunLight = dot(pn, sunSampleDir);
+						terminated = !(bounces < fc.max_bounces);
+						if (terminated) acc.w += 1.f; // kernel.cu:301
+						if (sunLight > 0.f) {
+							scolor = (sun_radiance(fc, sunSampleDir) * sunLight) * 1E-5f;
+							ro = hitp; rd = sunSampleDir;
+							shadow = true;
+							need_setup = true;
+						} else {
+							pstate = P_BOUNCE;
+						}
+					}
+				} else if (pstate == P_SHD_DONE) {
+					// ---- connect (kernel.cu:328-346): runs after shade within the same reference frame
+					const bool occluded = r.hit;
+					if (DBG) {
+						tally.shadow_rays++;
+						nsh++;
+						hsh = hmix(hsh, static_cast<uint32_t>(occluded));
+						if (occluded) {
+							hsh = hmix(hsh, static_cast<uint32_t>(info.brick_id));
+							hsh = hmix(hsh, static_cast<uint32_t>(info.sub_id) | (static_cast<uint32_t>(info.level) << 12));
+						}
+					}
+					if (!occluded) { acc.x += scolor.x; acc.y += scolor.y; acc.z += scolor.z; }
+					pstate = P_BOUNCE;
 				}
-				hseg = hmix(hseg, static_cast<uint32_t>(is_hit));
-				if (is_hit) {
-					hseg = hmix(hseg, __float_as_uint(distance));
-					hseg = hmix(hseg, pack_normal(normal) | (static_cast<uint32_t>(info.level) << 12));
-					hseg = hmix(hseg, static_cast<uint32_t>(info.brick_id));
-					hseg = hmix(hseg, static_cast<uint32_t>(info.sub_id));
-				}
-			}
-			if (fc.flags & 1u) { // BM_FLAG_PRIMARY_ONLY
-				if (!is_hit) {
-					const f3 c = throughput * sunsky_radiance(fc, direction);
-					acc.x += c.x; acc.y += c.y; acc.z += c.z;
-				}
-				acc.w += 1.f;
-				break;
-			}
-			// ---- shade (kernel.cu:242-325); frame = base_frame + bounce, queue slot = slot
-			const uint32_t frame = fc.base_frame + static_cast<uint32_t>(bounces);
-			uint32_t sseed = (frame * p * 147565741u) * 720898027u * slot;
-			if (!is_hit) {
-				const f3 c = throughput * (bounces == 0 ? sunsky_radiance(fc, direction) : sky_radiance(fc, direction));
-				acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.f;
-				break;
-			}
-			origin = origin + direction * distance;
-			origin = origin + normal * 2.f * kEpsilon;
-			throughput = throughput * mk(1.f, 1.f, 1.f);
-			const f3 sunSampleDir = cone_sample(sunDir, fc.cone_extent, sseed);
-			const float sunLight = dot(normal, sunSampleDir);
-			const bool cast = sunLight > 0.f;
-			f3 scolor = mk(0.f, 0.f, 0.f);
-			if (cast) scolor = ((throughput * sun_radiance(fc, sunSampleDir)) * sunLight) * 1E-5f;
-			const f3 shadow_origin = origin;
-			bool terminated = false;
-			if (bounces < fc.max_bounces) {
-				const float r1 = 2.f * kPi * random_float(sseed);
-				const float r2 = random_float(sseed);
-				const float r2s = sqrtf(r2);
-				// computeOrthonormalBasisNaive (kernel.cu:76-84)
-				f3 u = fabs(static_cast<double>(normal.x)) > .9 ? mk(0.0f, 1.0f, 0.0f) : mk(1.0f, 0.0f, 0.0f);
-				u = normalize(cross(u, normal));
-				const f3 v = cross(normal, u);
-				float sn, cs;
-				det_sincos(r1, sn, cs);
-				direction = normalize(((u * cs) * r2s + (v * sn) * r2s) + normal * sqrtf(1 - r2));
-				bounces++;
-			} else {
-				acc.w += 1.f; // kernel.cu:301
-				terminated = true;
-			}
-			// ---- connect (kernel.cu:328-346): runs after shade within the same reference frame
-			if (cast) {
-				f3 yn = mk(0.f, 0.f, 0.f);
-				float t = 0.f;
-				HitInfo sinfo;
-				const bool occluded = intersect_voxel<DBG>(sc, fc.campos[0], fc.campos[1], fc.campos[2], shadow_origin, sunSampleDir, yn, t, sinfo, tally);
-				if (DBG) {
-					tally.shadow_rays++;
-					nsh++;
-					hsh = hmix(hsh, static_cast<uint32_t>(occluded));
-					if (occluded) {
-						hsh = hmix(hsh, static_cast<uint32_t>(sinfo.brick_id));
-						hsh = hmix(hsh, static_cast<uint32_t>(sinfo.sub_id) | (static_cast<uint32_t>(sinfo.level) << 12));
+				if (pstate == P_BOUNCE) {
+					if (!terminated) { // kernel.cu:281-299: cosine-weighted bounce; the two draws follow the cone sample's
+						const float r1 = 2.f * kPi * random_float(sseed);
+						const float r2 = random_float(sseed);
+						const float r2s = sqrtf(r2);
+						// computeOrthonormalBasisNaive (kernel.cu:76-84)
+						f3 u = fabs(static_cast<double>(pn.x)) > .9 ? mk(0.0f, 1.0f, 0.0f) : mk(1.0f, 0.0f, 0.0f);
+						u = normalize(cross(u, pn));
+						const f3 v = cross(pn, u);
+						float sn, cs;
+						det_sincos(r1, sn, cs);
+						pdir = normalize(((u * cs) * r2s + (v * sn) * r2s) + pn * sqrtf(1 - r2));
+						bounces++;
+						ro = hitp; rd = pdir;
+						r.n = pn;
+						shadow = false;
+						need_setup = true;
+					} else {
+						s++;
+						pstate = P_GEN;
 					}
 				}
-				if (!occluded) { acc.x += scolor.x; acc.y += scolor.y; acc.z += scolor.z; }
+				if (pstate == P_GEN) {
+					if (s >= fc.spp) {
+						state = ST_FIN;
+					} else {
+						// ---- primary_rays (kernel.cu:157-200) for queue slot `slot`, start_position 0
+						slot = p + static_cast<uint32_t>(fc.sample_base + s) * W * H;
+						uint32_t seed = (fc.base_frame * 147565741u) * 720898027u * slot;
+						const f3 cam_right = ld3(fc.right), cam_up = ld3(fc.up), cam_dir = ld3(fc.dir), cam_o = ld3(fc.origin);
+						// Random2DStratifiedSample (kernel.cu:40-61)
+						const int stratum = static_cast<int>(random_float(seed) * (16 + 0.99999f));
+						const int stratumX = stratum % 4, stratumY = (stratum / 4) % 4;
+						const float jx = 0.25f * stratumX + (random_float(seed) * 0.25f);
+						const float jy = 0.25f * stratumY + (random_float(seed) * 0.25f);
+						const float ppx = static_cast<float>(static_cast<uint32_t>(x)) - jx;
+						const float ppy = static_cast<float>(static_cast<uint32_t>(y)) - jy;
+						const float ni = (ppx / static_cast<float>(W)) - 0.5f;
+						const float nj = ((static_cast<float>(H) - ppy) / static_cast<float>(H)) - 0.5f;
+						const f3 to_focal = normalize(cam_dir + cam_right * ni + cam_up * nj);
+						const f3 convergence = cam_o + to_focal * fc.focal3;
+						const float l0 = random_float(seed); // canonical order: left to right
+						const float l1 = random_float(seed);
+						float lx = 0.f, lyy = 0.f;
+						{ // ConcentricSampleDisk (kernel.cu:85-103)
+							const float ox = 2.f * l0 - 1.f, oy = 2.f * l1 - 1.f;
+							if (!(ox == 0 && oy == 0)) {
+								float theta, rr;
+								if (fabsf(ox) > fabsf(oy)) { rr = ox; theta = kPi / 4 * (oy / ox); }
+								else { rr = oy; theta = kPi / 2 - kPi / 4 * (ox / oy); }
+								float sn, cs;
+								det_sincos(theta, sn, cs);
+								lx = rr * cs;
+								lyy = rr * sn;
+							}
+						}
+						const float plx = fc.lens_radius * lx, ply = fc.lens_radius * lyy;
+						hitp = cam_o + cam_right * plx + cam_up * ply;
+						pdir = normalize(convergence - hitp);
+						pn = mk(0.f, 0.f, 0.f);
+						bounces = 0;
+						terminated = false;
+						if (DBG) tally.paths++;
+						ro = hitp; rd = pdir;
+						r.n = pn;
+						shadow = false;
+						need_setup = true;
+					}
+				}
+				if (need_setup) {
+					if (shadow) r.n = mk(0.f, 0.f, 0.f); // connect passes a zeroed normal (kernel.cu:338)
+					pstate = shadow ? P_SHD_DONE : P_EXT_DONE;
+					state = ray_setup<DBG>(sc, ro, rd, r, tally);
+				}
 			}
-			if (terminated) break;
+		} else if (nB >= quorum || nA == 0) {
+			// ================= phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask DDA, streaming request)
+			if (state == ST_CAND) state = process_candidate<DBG>(sc, fc.campos, r, info, tally);
+		} else {
+			// ================= phase A: brick-grid DDA moves; lanes that reach a non-empty cell or leave the grid wait
+#pragma unroll 1
+			for (int k = 0; k < 4; ++k)
+				if (state == ST_OUTER) state = outer_step<DBG>(sc, r, tally);
 		}
 	}
 	if (valid) accum[local_pixel] = acc;
@@ -504,7 +650,7 @@ __global__ void upload_bricks(const DeviceScene sc, const uint32_t* __restrict__
 	const int sci = (px / 16) + (py / 16) * sc.sg_xy + (pz / 16) * sc.sg_xy2;
 	const uint32_t local = static_cast<uint32_t>((px % 16) + (py % 16) * 16 + (pz % 16) * 256);
 	const uint32_t word = indices_queue[i];
-	const uint32_t slot = sc.brick_base[sci] + (word & kIndexBits);
+	const uint32_t slot = sc.super_info[sci].brick_base + (word & kIndexBits);
 	arena_rw[(static_cast<size_t>(slot) << 4) + w] = bricks_queue[(static_cast<size_t>(i) << 4) + w];
 	if (w == 0) sc.index_grid[(static_cast<size_t>(sci) << 12) + local] = word; // plain store: clears unloaded + requested
 }

@@ -117,6 +117,8 @@ void World::build_supercell(int sx, int sy, int sz, const float* heights) {
 	cell.indices.assign(kCellsPerSupercell, 0u);
 	cell.bricks.clear();
 	cell.resident = 0;
+	cell.coarse_mask = 0;
+	for (auto& m : cell.fine_mask) m = 0;
 
 	// per brick column: lowest / highest terrain height under its 8x8 footprint
 	float lo[kSupercell * kSupercell], hi[kSupercell * kSupercell];
@@ -159,6 +161,9 @@ void World::build_supercell(int sx, int sy, int sz, const float* heights) {
 						}
 				}
 				cell.bricks.push_back(brick);
+				const int block = (bx >> 2) + 4 * (by >> 2) + 16 * (bz >> 2);
+				cell.coarse_mask |= 1ull << block;
+				cell.fine_mask[block] |= 1ull << ((bx & 3) + 4 * (by & 3) + 16 * (bz & 3));
 				cell.indices[bx + by * kSupercell + bz * kSupercell * kSupercell] =
 					static_cast<uint32_t>(cell.bricks.size() - 1) | 0x80000000u | (lod << 12); // Scene.cpp:104
 			}

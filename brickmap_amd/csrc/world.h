@@ -22,6 +22,9 @@ struct HostSupercell {               // Scene::Supercell, Scene.h:21-29 (host pa
 	std::vector<uint32_t> indices;   // 4096 words: slot | loaded | lod<<12, 0 = empty brick
 	std::vector<Brick> bricks;       // non-empty bricks in generation order
 	uint32_t resident = 0;           // gpu_index_highest: next free slot of this supercell's arena region
+	// occupancy summary for the GPU traversal: which 4x4x4-brick blocks / which bricks are non-empty
+	uint64_t coarse_mask = 0;
+	uint64_t fine_mask[64] = {};
 };
 
 struct WorldDims {
