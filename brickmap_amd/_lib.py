@@ -56,6 +56,13 @@ class bm_counters(C.Structure):
         return {n: int(getattr(self, n)) for n in COUNTER_NAMES}
 
 
+SCHED_NAMES = ("step_runs", "step_lanes", "candidate_runs", "candidate_lanes", "shade_runs", "shade_lanes", "waves", "reserved")
+
+
+class bm_sched_stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in SCHED_NAMES]
+
+
 # every symbol include/brickmap.h declares: name -> (restype, argtypes)
 _vp, _i, _u32p = C.c_void_p, C.c_int, C.POINTER(C.c_uint32)
 SIGNATURES = {
@@ -91,6 +98,7 @@ SIGNATURES = {
     "bm_render_times": (_i, [_vp, _vp, _i, C.POINTER(C.c_int)]),
     "bm_counters_read": (_i, [_vp, C.POINTER(bm_counters)]),
     "bm_counters_reset": (_i, [_vp]),
+    "bm_sched_stats_read": (_i, [_vp, C.POINTER(bm_sched_stats)]),
     "bm_debug_sincos": (_i, [_i, _i, _vp, _vp, _vp]),
     "bm_debug_sky": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp]),
 }

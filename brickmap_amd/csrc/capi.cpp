@@ -172,6 +172,7 @@ int bm_last_render_ms(bm_scene* scene, float* ms) { BM_NEED(scene); return scene
 int bm_render_times(bm_scene* scene, float* ms, int capacity, int* count) { BM_NEED(scene); return scene->impl.render_times(ms, capacity, count); }
 int bm_counters_read(bm_scene* scene, bm_counters* out) { BM_NEED(scene); return scene->impl.counters_read(out); }
 int bm_counters_reset(bm_scene* scene) { BM_NEED(scene); return scene->impl.counters_reset(); }
+int bm_sched_stats_read(bm_scene* scene, bm_sched_stats* out) { BM_NEED(scene); return scene->impl.sched_stats_read(out); }
 
 int bm_debug_sincos(int device, int n, const float* x_host, float* sin_host, float* cos_host) {
 	if (n <= 0 || !x_host || !sin_host || !cos_host) { set_error("bad argument"); return BM_EINVAL; }

@@ -69,8 +69,9 @@ struct FrameConstants {
 	int tiles_x, tiles_y, stripe_w; // 16x16-pixel tiles; stripe_w = tile columns per XCD
 };
 
-struct DeviceCounters { // same order as bm_counters
+struct DeviceCounters { // v: same order as bm_counters; sched: same order as bm_sched_stats
 	unsigned long long v[8];
+	unsigned long long sched[8];
 };
 
 } // namespace bm

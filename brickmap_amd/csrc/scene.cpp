@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -113,6 +114,7 @@ Scene::~Scene() {
 	if (d_indices_queue_) hipFree(d_indices_queue_);
 	if (d_load_count_) hipFree(d_load_count_);
 	if (d_counters_) hipFree(d_counters_);
+	if (d_work_counter_) hipFree(d_work_counter_);
 	for (int i = 0; i < kTimingRing; ++i) {
 		if (ev_start_[i]) hipEventDestroy(ev_start_[i]);
 		if (ev_stop_[i]) hipEventDestroy(ev_stop_[i]);
@@ -140,6 +142,12 @@ int Scene::init(int grid_size, int grid_height) {
 	BM_HIP(hipMemset(d_load_count_, 0, sizeof(uint32_t)));
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_counters_), sizeof(DeviceCounters)));
 	BM_HIP(hipMemset(d_counters_, 0, sizeof(DeviceCounters)));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_work_counter_), sizeof(uint32_t)));
+	hipDeviceProp_t prop;
+	BM_HIP(hipGetDeviceProperties(&prop, device_));
+	compute_units_ = prop.multiProcessorCount; // main.cpp:97 sm_cores
+	blocks_per_cu_[0] = trace_blocks_per_cu(false);
+	blocks_per_cu_[1] = trace_blocks_per_cu(true);
 	return alloc_queue();
 }
 
@@ -380,8 +388,10 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 	}
 	const bool instrumented = dbg != nullptr || (fp->flags & BM_FLAG_COUNTERS);
 	const int slot = static_cast<int>(launches_ % kTimingRing);
+	BM_HIP(hipMemsetAsync(d_work_counter_, 0, sizeof(uint32_t), stream)); // chunk counter of the persistent kernel
 	BM_HIP(hipEventRecord(ev_start_[slot], stream));
-	launch_trace(view_, fc, accum, dbg, (fp->flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr, instrumented, stream);
+	launch_trace(view_, fc, accum, dbg, (fp->flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr, d_work_counter_, instrumented,
+				 compute_units_ * blocks_per_cu_[instrumented ? 1 : 0], stream);
 	BM_HIP(hipGetLastError());
 	BM_HIP(hipEventRecord(ev_stop_[slot], stream));
 	launches_++;
@@ -432,8 +442,17 @@ int Scene::counters_read(bm_counters* out) {
 	if (!out) { set_error("null argument"); return BM_EINVAL; }
 	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipDeviceSynchronize());
-	static_assert(sizeof(bm_counters) == sizeof(DeviceCounters), "counter blocks must match");
-	BM_HIP(hipMemcpy(out, d_counters_, sizeof(DeviceCounters), hipMemcpyDeviceToHost));
+	static_assert(sizeof(bm_counters) == sizeof(DeviceCounters::v), "counter blocks must match");
+	BM_HIP(hipMemcpy(out, d_counters_, sizeof(bm_counters), hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int Scene::sched_stats_read(bm_sched_stats* out) {
+	if (!out) { set_error("null argument"); return BM_EINVAL; }
+	BM_HIP(hipSetDevice(device_));
+	BM_HIP(hipDeviceSynchronize());
+	static_assert(sizeof(bm_sched_stats) == sizeof(DeviceCounters::sched), "scheduler stat blocks must match");
+	BM_HIP(hipMemcpy(out, reinterpret_cast<const char*>(d_counters_) + offsetof(DeviceCounters, sched), sizeof(bm_sched_stats), hipMemcpyDeviceToHost));
 	return 0;
 }
 

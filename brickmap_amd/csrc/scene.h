@@ -47,6 +47,7 @@ public:
 	int render_times(float* ms, int capacity, int* count); // durations of the most recent launches, oldest first
 	int counters_read(bm_counters* out);
 	int counters_reset();
+	int sched_stats_read(bm_sched_stats* out);
 
 	World world;
 	int device() const { return device_; }
@@ -78,6 +79,8 @@ private:
 	uint32_t* d_bricks_queue_ = nullptr;
 	uint32_t* d_indices_queue_ = nullptr;
 	DeviceCounters* d_counters_ = nullptr;
+	uint32_t* d_work_counter_ = nullptr; // chunk counter of the persistent trace kernel, zeroed before each launch
+	int compute_units_ = 0, blocks_per_cu_[2] = {0, 0};
 	// pinned staging (Scene.cpp:30-32)
 	int* h_positions_ = nullptr;
 	uint32_t* h_bricks_ = nullptr;

@@ -137,7 +137,6 @@ struct RayState {
 	unsigned long long coarse, fine;
 	uint32_t brick_base;
 	int sci;
-	int guard;
 	float distance;     // result
 	bool hit;
 };
@@ -204,8 +203,6 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 	r.tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
 	r.dx = static_cast<float>(r.sx) * rx; r.dy = static_cast<float>(r.sy) * ry; r.dz = static_cast<float>(r.sz) * rz;
 	r.axis = -1;
-	// a well-formed ray makes at most 2*cells + cells_h steps; the bound only protects the GPU from NaN input
-	r.guard = 4 * (2 * cells + cells_h) + 16;
 	load_super(sc, r);
 	load_block(sc, r);
 	if (DBG) tally.index_loads++; // one per visited cell = the reference's index loads (algorithmic count)
@@ -213,34 +210,35 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 }
 
 // voxel.cuh:249-258: one Amanatides-Woo move to the next cell.  Returns the next state.
+// Written select-style (no per-axis branches): the only divergent region is the block / supercell
+// boundary crossing.  `t += mask ? delta : 0` is the reference's `tmax += mask * tdelta` for finite deltas.
 template <bool DBG>
 __device__ __forceinline__ int outer_step(const DeviceScene& sc, RayState& r, Tally& tally) {
-	const bool mx = r.tx < r.ty && r.tx < r.tz;
-	const bool my = !mx && r.ty <= r.tx && r.ty < r.tz;
-	bool reload_super = false, reload_block = false, left = false;
+	// work on scalar copies: selects between struct members would otherwise pin the struct in scratch memory
+	const float tx = r.tx, ty = r.ty, tz = r.tz;
+	const int sx = r.sx, sy = r.sy, sz = r.sz;
+	const bool mx = tx < ty && tx < tz;
+	const bool my = ty <= tx && ty < tz; // mx implies !my
+	const bool mz = !(mx || my);
+	const int npx = r.px + (mx ? sx : 0);
+	const int npy = r.py + (my ? sy : 0);
+	const int npz = r.pz + (mz ? sz : 0);
+	r.px = npx; r.py = npy; r.pz = npz;
+	r.tx = tx + (mx ? r.dx : 0.f);
+	r.ty = ty + (my ? r.dy : 0.f);
+	r.tz = tz + (mz ? r.dz : 0.f);
+	r.axis = mx ? 0 : (my ? 1 : 2);
+	const int s_sel = mx ? sx : (my ? sy : sz);
+	const int c = mx ? npx : (my ? npy : npz);
 	// a move along -axis crosses a 4- / 16-aligned boundary when the NEW coordinate + 1 is aligned
-	if (mx) {
-		r.axis = 0;
-		r.px += r.sx;
-		const int c = r.px + (r.sx < 0 ? 1 : 0);
-		if ((c & 3) == 0) { reload_block = true; if ((c & 15) == 0) { left = r.px == (r.sx > 0 ? sc.cells : -1); reload_super = true; } }
-		r.tx += r.dx;
-	} else if (my) {
-		r.axis = 1;
-		r.py += r.sy;
-		const int c = r.py + (r.sy < 0 ? 1 : 0);
-		if ((c & 3) == 0) { reload_block = true; if ((c & 15) == 0) { left = r.py == (r.sy > 0 ? sc.cells : -1); reload_super = true; } }
-		r.ty += r.dy;
-	} else {
-		r.axis = 2;
-		r.pz += r.sz;
-		const int c = r.pz + (r.sz < 0 ? 1 : 0);
-		if ((c & 3) == 0) { reload_block = true; if ((c & 15) == 0) { left = r.pz == (r.sz > 0 ? sc.cells_height : -1); reload_super = true; } }
-		r.tz += r.dz;
-	}
-	if (left || --r.guard <= 0) return ST_NEED; // left the grid: the ray missed (r.hit stays false)
-	if (reload_block) {
-		if (reload_super) load_super(sc, r);
+	const int ce = c - (s_sel >> 31);
+	if ((ce & 3) == 0) {
+		if ((ce & 15) == 0) {
+			// supercell boundary; the world edge is one of them, so the exit test (voxel.cuh:256) lives here
+			const int lim = mz ? sc.cells_height : sc.cells;
+			if (c == (s_sel > 0 ? lim : -1)) return ST_NEED; // left the grid: miss (r.hit stays false)
+			load_super(sc, r);
+		}
 		load_block(sc, r);
 	}
 	if (DBG) tally.index_loads++;
@@ -313,59 +311,61 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	return ST_OUTER; // nothing solid along the ray inside this brick: keep walking
 }
 
-// ---- sky model (sunsky.cu:10-161); view-independent terms arrive precomputed in FrameConstants
-struct SkyTerms {
-	f3 Fex, somethingElse;
+// ---- sky model (sunsky.cu:10-161); view-independent terms arrive precomputed in FrameConstants.
+// Split so that lanes shading a sun sample (sun()) and lanes shading a miss (sky() / sunsky()) share the
+// extinction term.  RayleighPhase / hgPhase (sunsky.cu:10-12,20-22) contain double literals in the
+// reference; they are evaluated in fp32 here (difference ~1e-6 relative, inside the 1e-4 radiance bar).
+struct SkyView {
+	f3 Fex;           // combined extinction factor
 	float cosViewSun;
 };
-__device__ __forceinline__ SkyTerms sky_terms(const FrameConstants& fc, f3 viewDir) {
-	const f3 sunDir = ld3(fc.sun_direction);
-	SkyTerms o;
-	o.cosViewSun = dot(viewDir, sunDir);
+__device__ __forceinline__ SkyView sky_view(const FrameConstants& fc, f3 viewDir) {
+	SkyView o;
+	o.cosViewSun = dot(viewDir, ld3(fc.sun_direction));
 	const float cosUpView = dot(mk(0.f, 0.f, 1.f), viewDir);
 	const float zenith = gmax(0.0f, cosUpView);
 	const float rayleighLen = 8.4E3f / zenith;
 	const float mieLen = 1.25E3f / zenith;
-	const f3 ray = ld3(fc.rayleigh), mie = ld3(fc.mie);
-	const f3 a = ray * rayleighLen + mie * mieLen;
+	const f3 a = ld3(fc.rayleigh) * rayleighLen + ld3(fc.mie) * mieLen;
 	o.Fex = mk(expf(-a.x), expf(-a.y), expf(-a.z));
-	// RayleighPhase (sunsky.cu:10-12) and hgPhase (:20-22) evaluate in double because of their double literals
-	const double c = static_cast<double>(o.cosViewSun);
-	const float rayleighPhase = static_cast<float>((3.0 / (16.0 * static_cast<double>(kPi))) * (1.0 + static_cast<double>(o.cosViewSun * o.cosViewSun)));
-	const double g = static_cast<double>(0.80f);
-	const double g2 = static_cast<double>(0.80f * 0.80f);
-	const double base = 1.0 - 2.0 * g * c + g2;
-	const float hg = static_cast<float>((1.0 / (4.0 * static_cast<double>(kPi))) * ((1.0 - g2) / (base * sqrt(base))));
-	const f3 light = ray * rayleighPhase + mie * hg;
-	o.somethingElse = (light / ld3(fc.total)) * fc.sunE;
 	return o;
 }
-__device__ __forceinline__ f3 sky_body(const FrameConstants& fc, const SkyTerms& t) {
-	f3 sky = t.somethingElse * mk(1.0f - t.Fex.x, 1.0f - t.Fex.y, 1.0f - t.Fex.z);
-	const f3 q = t.somethingElse * t.Fex;
+// in-scattered sky light: `sky` of sunsky.cu:109-111 (before the 0.01 / SkyFactor scaling)
+__device__ __forceinline__ f3 sky_scatter(const FrameConstants& fc, const SkyView& v) {
+	const float c = v.cosViewSun;
+	const float rayleighPhase = (3.0f / (16.0f * kPi)) * (1.0f + c * c);
+	const float g = 0.80f, g2 = 0.80f * 0.80f;
+	const float base = 1.0f - 2.0f * g * c + g2;
+	const float hg = (1.0f / (4.0f * kPi)) * ((1.0f - g2) / (base * sqrtf(base)));
+	const f3 light = ld3(fc.rayleigh) * rayleighPhase + ld3(fc.mie) * hg;
+	const f3 somethingElse = (light / ld3(fc.total)) * fc.sunE;
+	const f3 sky = somethingElse * mk(1.0f - v.Fex.x, 1.0f - v.Fex.y, 1.0f - v.Fex.z);
+	const f3 q = somethingElse * v.Fex;
 	const f3 p = mk(sqrtf(q.x), sqrtf(q.y), sqrtf(q.z)); // pow(x, 0.5)
 	const float a = fc.mixf;
 	return sky * mk(1.0f * (1.0f - a) + p.x * a, 1.0f * (1.0f - a) + p.y * a, 1.0f * (1.0f - a) + p.z * a);
 }
-__device__ __forceinline__ f3 sun_radiance(const FrameConstants& fc, f3 viewDir) { // sun(), sunsky.cu:32-74
-	const SkyTerms t = sky_terms(fc, viewDir);
+__device__ __forceinline__ f3 sun_from_view(const FrameConstants& fc, const SkyView& v) { // sun(), sunsky.cu:32-74
 	// quirk kept: `sunAngularDiameterCos < (cosViewSunAngle ? 1.0 : 0.0)` tests cos != 0
-	const float sundisk = static_cast<double>(fc.sun_angular_cos) < (t.cosViewSun != 0.0f ? 1.0 : 0.0) ? 1.0f : 0.0f;
-	return ((t.Fex * (fc.sunE * 19000.0f)) * sundisk) * 0.01f;
+	const float sundisk = static_cast<double>(fc.sun_angular_cos) < (v.cosViewSun != 0.0f ? 1.0 : 0.0) ? 1.0f : 0.0f;
+	return ((v.Fex * (fc.sunE * 19000.0f)) * sundisk) * 0.01f;
 }
-__device__ __forceinline__ f3 sky_radiance(const FrameConstants& fc, f3 viewDir) { // sky(), sunsky.cu:76-114
-	const SkyTerms t = sky_terms(fc, viewDir);
-	return sky_body(fc, t) * (1.f * 0.01f);
+__device__ __forceinline__ f3 sky_from_view(const FrameConstants& fc, const SkyView& v) { // sky(), sunsky.cu:76-114
+	return sky_scatter(fc, v) * (1.f * 0.01f);
 }
-__device__ __forceinline__ f3 sunsky_radiance(const FrameConstants& fc, f3 viewDir) { // sunsky(), sunsky.cu:116-161
-	if (fc.sun_angular_cos == 1.0f) return mk(1.0f, 0.0f, 0.0f);
-	const SkyTerms t = sky_terms(fc, viewDir);
-	const f3 sky = sky_body(fc, t);
+__device__ __forceinline__ f3 sunsky_from_view(const FrameConstants& fc, const SkyView& v) { // sunsky(), sunsky.cu:116-161
+	const f3 sky = sky_scatter(fc, v);
 	const float e0 = fc.sun_angular_cos, e1 = fc.sun_angular_cos + 0.00002f;
-	const float s = gmin(gmax((t.cosViewSun - e0) / (e1 - e0), 0.0f), 1.0f);
+	const float s = gmin(gmax((v.cosViewSun - e0) / (e1 - e0), 0.0f), 1.0f);
 	const float sundisk = s * s * (3.0f - 2.0f * s);
-	const f3 sun = ((t.Fex * (fc.sunE * 19000.0f)) * sundisk) * 1E-5f;
+	const f3 sun = ((v.Fex * (fc.sunE * 19000.0f)) * sundisk) * 1E-5f;
 	return (sun + sky) * 0.01f;
+}
+__device__ __forceinline__ f3 sun_radiance(const FrameConstants& fc, f3 viewDir) { return sun_from_view(fc, sky_view(fc, viewDir)); }
+__device__ __forceinline__ f3 sky_radiance(const FrameConstants& fc, f3 viewDir) { return sky_from_view(fc, sky_view(fc, viewDir)); }
+__device__ __forceinline__ f3 sunsky_radiance(const FrameConstants& fc, f3 viewDir) {
+	if (fc.sun_angular_cos == 1.0f) return mk(1.0f, 0.0f, 0.0f); // sunsky.cu:121-123
+	return sunsky_from_view(fc, sky_view(fc, viewDir));
 }
 
 // getConeSample (sunsky.cu:163-183)
@@ -403,46 +403,47 @@ __device__ __forceinline__ uint32_t pack_normal(f3 n) {
 
 } // namespace
 
-// Path state machine.  Each lane owns one pixel and walks through
+// Persistent-wave path tracer.
+//
+// Work distribution: the shard's pixels are cut into 4x4-pixel chunks (ordered so that four consecutive
+// chunks form an 8x8 block and sixteen a 16x16 tile).  Waves are persistent: whenever 16 or more of a
+// wave's lanes have no pixel, the wave takes that many chunks from a global counter (one atomic per
+// refill) and hands one pixel to each idle lane.  A lane traces ALL samples of its pixel, in order, before
+// it takes another one, so each pixel's accumulation order is fixed (sample by sample, event by event).
+//
+// Path state machine per lane:
 //   GEN -> [extend ray] -> EXT_DONE (shade) -> [shadow ray] -> SHD_DONE (connect) -> BOUNCE -> [extend ray] ...
-// A 64-lane wave interleaves three kinds of work, each run only when enough lanes want it (or nothing
-// else can run), so that the expensive, rarely-needed code never executes for a handful of lanes:
+// A wave interleaves three kinds of work, each run only when enough lanes want it (or nothing else can
+// run), so that the expensive, rarely-needed code never executes for a handful of lanes:
 //   phase A  one brick-grid DDA move            lanes in ST_OUTER   (cheap, most of the work)
 //   phase B  index word + 8^3 / 2^3 bitmask DDA  lanes in ST_CAND    (expensive, ~2.5 per ray)
 //   phase C  shade / connect / next ray + setup  lanes in ST_NEED    (expensive, once per ray)
 // Scheduling changes only WHEN a lane's operations happen, never their operands, so results are
 // identical to the reference's per-ray functions run one ray at a time (the oracle).
 enum : int { P_GEN = 0, P_EXT_DONE = 1, P_SHD_DONE = 2, P_BOUNCE = 3 };
+enum : int { ST_IDLE = 4 };
 
 template <bool DBG>
 __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const FrameConstants fc, float4* __restrict__ accum,
-												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters) {
-	// XCD-aware tile assignment: vertical stripes of tile columns per XCD
-	const int b = blockIdx.x;
-	const int xcd = b & 7, j = b >> 3;
-	const int tile_x = xcd * fc.stripe_w + (j % fc.stripe_w);
-	const int tile_y = j / fc.stripe_w;
-	if (tile_x >= fc.tiles_x || tile_y >= fc.tiles_y) return;
-	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const int x = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
-	const int ly = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3); // row inside this shard's packed buffer
-	const int y = ((ly / fc.band_rows) * fc.shard_count + fc.shard_rank) * fc.band_rows + ly % fc.band_rows;
-	// lanes outside the image stay alive (they only skip the work) so that wave-wide votes are well defined
-	const bool valid = x < fc.width && ly < fc.local_rows && y < fc.height;
-
+												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters,
+												  uint32_t* __restrict__ work_counter) {
+	const int lane = threadIdx.x & 63;
 	const uint32_t W = static_cast<uint32_t>(fc.width), H = static_cast<uint32_t>(fc.height);
-	const uint32_t p = static_cast<uint32_t>(y) * W + static_cast<uint32_t>(x); // global pixel index
-	const size_t local_pixel = static_cast<size_t>(ly) * W + static_cast<size_t>(x);
-	float4 acc = valid ? accum[local_pixel] : make_float4(0.f, 0.f, 0.f, 0.f);
+	const uint32_t total_chunks = static_cast<uint32_t>(fc.tiles_x) * static_cast<uint32_t>(fc.tiles_y) * 16u;
 
+	// per-pixel state
+	int x = 0, y = 0;
+	uint32_t p = 0;          // global pixel index y*W + x
+	size_t local_pixel = 0;  // index into this shard's packed buffers
+	float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 	Tally tally;
 	HitInfo info;
-	uint32_t d0 = 0, d1 = 0, d2 = 0xFFFFFFFFu, d3 = 0, hseg = 2166136261u, hsh = 2166136261u, next = 0, nsh = 0;
+	uint32_t d0 = 0, d1 = 0, d2 = 0xFFFFFFFFu, d3 = 0, hseg = 2166136261u, hsh = 2166136261u, next = 0, nsh = 0, loads0 = 0;
 
 	RayState r;
 	r.hit = false;
 	r.n = mk(0.f, 0.f, 0.f);
-	int state = valid ? ST_NEED : ST_FIN;
+	int state = ST_IDLE;
 	int pstate = P_GEN;
 	int s = 0;               // sample being traced
 	int bounces = 0;
@@ -454,15 +455,65 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 	f3 pdir = mk(0.f, 0.f, 0.f);   // direction of the extend ray in flight (RayQueue::direction)
 	f3 scolor = mk(0.f, 0.f, 0.f); // ShadowQueue::color
 
+	bool work_left = true;
+	// hang guard only (NaN directions): no wave needs more scheduler rounds than this
+	long long rounds_left = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fc.spp) + 1) * (fc.max_bounces + 2) *
+							(2ll * sc.cells + sc.cells_height + 64);
+	uint32_t runsA = 0, lanesA = 0, runsB = 0, lanesB = 0, runsC = 0, lanesC = 0; // wave-uniform scheduler statistics
+
 	for (;;) {
+		// ---- refill: hand pixels to idle lanes, 16 (one 4x4 chunk) at a time
+		const unsigned long long idle = __ballot(state == ST_IDLE);
+		const int nI = __popcll(idle);
+		if (work_left && nI >= 16) {
+			const int want = nI >> 4;
+			uint32_t base = 0;
+			if (lane == 0) base = atomicAdd(work_counter, static_cast<uint32_t>(want));
+			base = __builtin_amdgcn_readfirstlane(base);
+			if (base + want >= total_chunks) work_left = false;
+			const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
+			if (state == ST_IDLE && rank < want * 16) {
+				const uint32_t chunk = base + static_cast<uint32_t>(rank >> 4);
+				if (chunk < total_chunks) {
+					const uint32_t tile = chunk >> 4, k = chunk & 15u;
+					const int tile_x = static_cast<int>(tile % static_cast<uint32_t>(fc.tiles_x));
+					const int tile_y = static_cast<int>(tile / static_cast<uint32_t>(fc.tiles_x));
+					const int cx = static_cast<int>((k & 1u) | ((k >> 1) & 2u)), cy = static_cast<int>(((k >> 1) & 1u) | ((k >> 2) & 2u));
+					x = tile_x * 16 + cx * 4 + (rank & 3);
+					const int ly = tile_y * 16 + cy * 4 + ((rank >> 2) & 3); // row inside this shard's packed buffer
+					y = ((ly / fc.band_rows) * fc.shard_count + fc.shard_rank) * fc.band_rows + ly % fc.band_rows;
+					if (x < fc.width && ly < fc.local_rows && y < fc.height) {
+						p = static_cast<uint32_t>(y) * W + static_cast<uint32_t>(x);
+						local_pixel = static_cast<size_t>(ly) * W + static_cast<size_t>(x);
+						acc = accum[local_pixel];
+						s = 0;
+						pstate = P_GEN;
+						state = ST_NEED;
+						if (DBG) {
+							d0 = 0; d1 = 0; d2 = 0xFFFFFFFFu; d3 = 0; hseg = 2166136261u; hsh = 2166136261u; next = 0; nsh = 0;
+							loads0 = tally.index_loads;
+						}
+					}
+				}
+			}
+		}
 		const int nA = __popcll(__ballot(state == ST_OUTER));
 		const int nB = __popcll(__ballot(state == ST_CAND));
 		const int nC = __popcll(__ballot(state == ST_NEED));
 		const int live = nA + nB + nC;
-		if (live == 0) break;
-		const int quorum = (live + 2) / 3;
+		if (live == 0) {
+			if (!work_left || --rounds_left < 0) break;
+			continue; // everything idle but chunks remain (only pixels outside the image were handed out)
+		}
+		if (--rounds_left < 0) break;
+		// Policy: an expensive phase runs once a quarter of the live lanes wait for it (or nothing else can run);
+		// otherwise the DDA keeps moving.
+		const int quorum = (live + 3) / 4;
+		const bool runC = nC >= quorum || (nA == 0 && nB == 0);
+		const bool runA = !runC && !(nB >= quorum || nA == 0);
 
-		if (nC >= quorum || (nA == 0 && nB == 0)) {
+		if (runC) {
+			if (DBG) { runsC++; lanesC += nC; }
 			// ================= phase C: path logic for lanes whose ray just finished (or that need their first ray)
 			if (state == ST_NEED) {
 				bool need_setup = false;
@@ -488,38 +539,44 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 							hseg = hmix(hseg, static_cast<uint32_t>(info.sub_id));
 						}
 					}
-					if (fc.flags & 1u) { // BM_FLAG_PRIMARY_ONLY
-						if (!is_hit) {
-							const f3 c = sunsky_radiance(fc, pdir);
-							acc.x += c.x; acc.y += c.y; acc.z += c.z;
-						}
-						acc.w += 1.f;
-						s++;
-						pstate = P_GEN;
-					} else if (!is_hit) {
-						// ---- shade, miss branch (kernel.cu:316-323); throughput is identically (1,1,1) (kernel.cu:261,271)
-						const f3 c = bounces == 0 ? sunsky_radiance(fc, pdir) : sky_radiance(fc, pdir);
-						acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += 1.f;
-						s++;
-						pstate = P_GEN;
-					} else {
-						// ---- shade, hit branch (kernel.cu:255-302); frame = base_frame + bounce, queue slot = slot
+					const bool primary_only = fc.flags & 1u; // BM_FLAG_PRIMARY_ONLY
+					// direction whose sky terms are needed: the ray itself on a miss, the sun sample on a hit
+					f3 view = pdir;
+					float sunLight = 0.f;
+					bool cast = false;
+					if (is_hit && !primary_only) {
+						// ---- shade, hit branch (kernel.cu:255-302); frame = base_frame + bounce, queue slot = slot.
+						// throughput is identically (1,1,1) (kernel.cu:261,271) and is not carried.
 						const uint32_t frame = fc.base_frame + static_cast<uint32_t>(bounces);
 						sseed = (frame * p * 147565741u) * 720898027u * slot;
 						hitp = hitp + pdir * r.distance;
 						hitp = hitp + pn * 2.f * kEpsilon;
-						const f3 sunSampleDir = cone_sample(ld3(fc.sun_direction), fc.cone_extent, sseed);
-						const float sunLight = dot(pn, sunSampleDir);
+						view = cone_sample(ld3(fc.sun_direction), fc.cone_extent, sseed);
+						sunLight = dot(pn, view);
+						cast = sunLight > 0.f;
 						terminated = !(bounces < fc.max_bounces);
 						if (terminated) acc.w += 1.f; // kernel.cu:301
-						if (sunLight > 0.f) {
-							scolor = (sun_radiance(fc, sunSampleDir) * sunLight) * 1E-5f;
-							ro = hitp; rd = sunSampleDir;
+						if (!cast) pstate = P_BOUNCE;
+					}
+					if (!is_hit || cast) {
+						const SkyView sv = sky_view(fc, view);
+						if (cast) {
+							scolor = (sun_from_view(fc, sv) * sunLight) * 1E-5f; // kernel.cu:278
+							ro = hitp; rd = view;
 							shadow = true;
 							need_setup = true;
 						} else {
-							pstate = P_BOUNCE;
+							// ---- shade, miss branch (kernel.cu:316-323)
+							f3 c;
+							if (bounces == 0) c = fc.sun_angular_cos == 1.0f ? mk(1.0f, 0.0f, 0.0f) : sunsky_from_view(fc, sv);
+							else c = sky_from_view(fc, sv);
+							acc.x += c.x; acc.y += c.y; acc.z += c.z;
 						}
+					}
+					if (!is_hit || primary_only) { // the path ends here
+						acc.w += 1.f;
+						s++;
+						pstate = P_GEN;
 					}
 				} else if (pstate == P_SHD_DONE) {
 					// ---- connect (kernel.cu:328-346): runs after shade within the same reference frame
@@ -560,7 +617,14 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 				}
 				if (pstate == P_GEN) {
 					if (s >= fc.spp) {
-						state = ST_FIN;
+						// pixel finished: publish it and wait for the next one
+						accum[local_pixel] = acc;
+						if (DBG && dbg) {
+							uint32_t* d = dbg + local_pixel * 8;
+							d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = hseg; d[5] = hsh; d[6] = next | (nsh << 16);
+							d[7] = tally.index_loads - loads0;
+						}
+						state = ST_IDLE;
 					} else {
 						// ---- primary_rays (kernel.cu:157-200) for queue slot `slot`, start_position 0
 						slot = p + static_cast<uint32_t>(fc.sample_base + s) * W * H;
@@ -577,11 +641,14 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 						const float nj = ((static_cast<float>(H) - ppy) / static_cast<float>(H)) - 0.5f;
 						const f3 to_focal = normalize(cam_dir + cam_right * ni + cam_up * nj);
 						const f3 convergence = cam_o + to_focal * fc.focal3;
-						const float l0 = random_float(seed); // canonical order: left to right
-						const float l1 = random_float(seed);
-						float lx = 0.f, lyy = 0.f;
-						{ // ConcentricSampleDisk (kernel.cu:85-103)
-							const float ox = 2.f * l0 - 1.f, oy = 2.f * l1 - 1.f;
+						hitp = cam_o;
+						if (fc.lens_radius != 0.f) {
+							// thin-lens sample (kernel.cu:194-196).  With lens radius 0 the reference multiplies the disk
+							// sample by 0, and nothing downstream reads this seed again, so the draws can be skipped.
+							const float l0 = random_float(seed); // canonical order: left to right
+							const float l1 = random_float(seed);
+							float lx = 0.f, lyy = 0.f;
+							const float ox = 2.f * l0 - 1.f, oy = 2.f * l1 - 1.f; // ConcentricSampleDisk (kernel.cu:85-103)
 							if (!(ox == 0 && oy == 0)) {
 								float theta, rr;
 								if (fabsf(ox) > fabsf(oy)) { rr = ox; theta = kPi / 4 * (oy / ox); }
@@ -591,9 +658,9 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 								lx = rr * cs;
 								lyy = rr * sn;
 							}
+							const float plx = fc.lens_radius * lx, ply = fc.lens_radius * lyy;
+							hitp = cam_o + cam_right * plx + cam_up * ply;
 						}
-						const float plx = fc.lens_radius * lx, ply = fc.lens_radius * lyy;
-						hitp = cam_o + cam_right * plx + cam_up * ply;
 						pdir = normalize(convergence - hitp);
 						pn = mk(0.f, 0.f, 0.f);
 						bounces = 0;
@@ -611,31 +678,31 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 					state = ray_setup<DBG>(sc, ro, rd, r, tally);
 				}
 			}
-		} else if (nB >= quorum || nA == 0) {
+		} else if (!runA) {
+			if (DBG) { runsB++; lanesB += nB; }
 			// ================= phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask DDA, streaming request)
 			if (state == ST_CAND) state = process_candidate<DBG>(sc, fc.campos, r, info, tally);
 		} else {
 			// ================= phase A: brick-grid DDA moves; lanes that reach a non-empty cell or leave the grid wait
 #pragma unroll 1
-			for (int k = 0; k < 4; ++k)
+			for (int k = 0; k < 4; ++k) {
+				if (DBG) { runsA++; lanesA += __popcll(__ballot(state == ST_OUTER)); }
 				if (state == ST_OUTER) state = outer_step<DBG>(sc, r, tally);
+			}
 		}
 	}
-	if (valid) accum[local_pixel] = acc;
 
-	if (DBG) {
-		if (dbg && valid) {
-			uint32_t* d = dbg + local_pixel * 8;
-			d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = hseg; d[5] = hsh; d[6] = next | (nsh << 16); d[7] = tally.index_loads;
+	if (DBG && counters) { // wave-level sum, one atomic per wave and counter
+		unsigned long long v[8] = {tally.index_loads, tally.brick_tests, tally.byte_tests, tally.voxel_steps,
+								   tally.extend_rays, tally.shadow_rays, tally.requests, tally.paths};
+		for (int k = 0; k < 8; ++k) {
+			unsigned long long t = v[k];
+			for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+			if (lane == 0 && t) atomicAdd(&counters->v[k], t);
 		}
-		if (counters) { // wave-level sum, one atomic per wave and counter
-			unsigned long long v[8] = {tally.index_loads, tally.brick_tests, tally.byte_tests, tally.voxel_steps,
-									   tally.extend_rays, tally.shadow_rays, tally.requests, tally.paths};
-			for (int k = 0; k < 8; ++k) {
-				unsigned long long t = v[k];
-				for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-				if (lane == 0 && t) atomicAdd(&counters->v[k], t);
-			}
+		if (lane == 0) {
+			const unsigned long long st[7] = {runsA, lanesA, runsB, lanesB, runsC, lanesC, 1ull};
+			for (int k = 0; k < 7; ++k) atomicAdd(&counters->sched[k], st[k]);
 		}
 	}
 }
@@ -685,14 +752,27 @@ __global__ void debug_sky_kernel(const FrameConstants fc, int n, const float* __
 }
 
 // ---- host-callable launchers (kernels.h)
-void launch_trace(const DeviceScene& sc, const FrameConstants& fc, float* accum, uint32_t* dbg, DeviceCounters* counters, bool instrumented,
-				  hipStream_t stream) {
-	const int blocks = 8 * fc.stripe_w * fc.tiles_y;
-	if (blocks <= 0) return;
+int trace_blocks_per_cu(bool instrumented) {
+	int n = 0;
+	const hipError_t e = instrumented ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<true>, 256, 0)
+									  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<false>, 256, 0);
+	return e == hipSuccess && n > 0 ? n : 1;
+}
+
+// Persistent launch: exactly as many 256-thread workgroups as the device keeps resident (compute_units x
+// blocks per CU); the waves pull 4x4-pixel chunks from *work_counter, which must be zero at launch.
+void launch_trace(const DeviceScene& sc, const FrameConstants& fc, float* accum, uint32_t* dbg, DeviceCounters* counters, uint32_t* work_counter,
+				  bool instrumented, int resident_blocks, hipStream_t stream) {
+	const long long chunks = static_cast<long long>(fc.tiles_x) * fc.tiles_y * 16;
+	if (chunks <= 0) return;
+	long long blocks = (chunks + 15) / 16; // never more workgroups than 64-pixel groups
+	if (blocks > resident_blocks) blocks = resident_blocks;
 	if (instrumented)
-		hipLaunchKernelGGL(trace_paths<true>, dim3(blocks), dim3(256), 0, stream, sc, fc, reinterpret_cast<float4*>(accum), dbg, counters);
+		hipLaunchKernelGGL(trace_paths<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc, reinterpret_cast<float4*>(accum), dbg,
+						   counters, work_counter);
 	else
-		hipLaunchKernelGGL(trace_paths<false>, dim3(blocks), dim3(256), 0, stream, sc, fc, reinterpret_cast<float4*>(accum), nullptr, nullptr);
+		hipLaunchKernelGGL(trace_paths<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc, reinterpret_cast<float4*>(accum), nullptr,
+						   nullptr, work_counter);
 }
 
 void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const uint32_t* indices_queue, uint32_t* arena, uint32_t count,

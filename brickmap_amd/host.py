@@ -210,6 +210,12 @@ class Scene:
         check(self._L.bm_counters_read(self.gpuScene, C.byref(c)))
         return c.as_dict()
 
+    def sched_stats(self):
+        """Per-phase run / active-lane counts of the wave scheduler (instrumented launches only)."""
+        st = _lib.bm_sched_stats()
+        check(self._L.bm_sched_stats_read(self.gpuScene, C.byref(st)))
+        return {n: int(getattr(st, n)) for n in _lib.SCHED_NAMES}
+
     def counters_reset(self):
         check(self._L.bm_counters_reset(self.gpuScene))
 

@@ -86,6 +86,15 @@ typedef struct bm_counters {
 	uint64_t index_loads, brick_tests, byte_tests, voxel_steps, extend_rays, shadow_rays, requests, paths;
 } bm_counters;
 
+/* wave-scheduler statistics of the instrumented kernel (BM_FLAG_COUNTERS): how often each phase of the
+ * per-wave scheduler ran and with how many of the 64 lanes active (DESIGN.md "Wave scheduler") */
+typedef struct bm_sched_stats {
+	uint64_t step_runs, step_lanes;           /* phase A: brick-grid DDA moves       */
+	uint64_t candidate_runs, candidate_lanes; /* phase B: index word + bitmask DDA   */
+	uint64_t shade_runs, shade_lanes;         /* phase C: shade / connect / next ray */
+	uint64_t waves, reserved;
+} bm_sched_stats;
+
 /* ---- errors (replaces assert_cuda.h:5 / assert_cuda.cpp:3-13) */
 BM_API const char* bm_last_error_string(void);
 BM_API int bm_device_count(int* count);
@@ -154,6 +163,7 @@ BM_API int bm_last_render_ms(bm_scene* scene, float* ms);
 BM_API int bm_render_times(bm_scene* scene, float* ms, int capacity, int* count);
 BM_API int bm_counters_read(bm_scene* scene, bm_counters* out);
 BM_API int bm_counters_reset(bm_scene* scene);
+BM_API int bm_sched_stats_read(bm_scene* scene, bm_sched_stats* out);
 
 /* ---- numeric-contract probes used by the parity tests (device side of detmath.h etc.) */
 BM_API int bm_debug_sincos(int device, int n, const float* x_host, float* sin_host, float* cos_host);
