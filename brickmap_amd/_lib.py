@@ -56,7 +56,7 @@ class bm_counters(C.Structure):
         return {n: int(getattr(self, n)) for n in COUNTER_NAMES}
 
 
-SCHED_NAMES = ("step_runs", "step_lanes", "candidate_runs", "candidate_lanes", "shade_runs", "shade_lanes", "waves", "reserved")
+SCHED_NAMES = ("step_runs", "step_lanes", "candidate_runs", "candidate_lanes", "shade_runs", "shade_lanes", "connect_runs", "connect_lanes")
 
 
 class bm_sched_stats(C.Structure):

@@ -417,14 +417,21 @@ __device__ __forceinline__ uint32_t pack_normal(f3 n) {
 // run), so that the expensive, rarely-needed code never executes for a handful of lanes:
 //   phase A  one brick-grid DDA move            lanes in ST_OUTER   (cheap, most of the work)
 //   phase B  index word + 8^3 / 2^3 bitmask DDA  lanes in ST_CAND    (expensive, ~2.5 per ray)
-//   phase C  shade / connect / next ray + setup  lanes in ST_NEED    (expensive, once per ray)
+//   phase C  shade / next primary ray + setup    lanes in ST_NEED    (expensive, once per extend ray)
+//   phase D  connect + stored bounce ray setup   lanes in ST_CONN    (cheap, once per shadow ray)
 // Scheduling changes only WHEN a lane's operations happen, never their operands, so results are
 // identical to the reference's per-ray functions run one ray at a time (the oracle).
 enum : int { P_GEN = 0, P_EXT_DONE = 1, P_SHD_DONE = 2, P_BOUNCE = 3 };
-enum : int { ST_IDLE = 4 };
+enum : int { ST_IDLE = 4, ST_CONN = 5 };
 
+#ifndef BM_WAVES_PER_SIMD
+#define BM_WAVES_PER_SIMD 4
+#endif
+#ifndef BM_STEPS_PER_ROUND
+#define BM_STEPS_PER_ROUND 8
+#endif
 template <bool DBG>
-__global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const FrameConstants fc, float4* __restrict__ accum,
+__global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants fc, float4* __restrict__ accum,
 												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters,
 												  uint32_t* __restrict__ work_counter) {
 	const int lane = threadIdx.x & 63;
@@ -432,9 +439,9 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 	const uint32_t total_chunks = static_cast<uint32_t>(fc.tiles_x) * static_cast<uint32_t>(fc.tiles_y) * 16u;
 
 	// per-pixel state
-	int x = 0, y = 0;
-	uint32_t p = 0;          // global pixel index y*W + x
-	size_t local_pixel = 0;  // index into this shard's packed buffers
+	uint32_t xy = 0;          // x | y << 16
+	uint32_t p = 0;           // global pixel index y*W + x
+	uint32_t local_pixel = 0; // index into this shard's packed buffers
 	float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 	Tally tally;
 	HitInfo info;
@@ -449,17 +456,16 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 	int bounces = 0;
 	bool shadow = false;     // kind of the ray in flight
 	bool terminated = false; // path ends after its pending shadow ray
-	uint32_t slot = 0, sseed = 0;
 	f3 hitp = mk(0.f, 0.f, 0.f);   // surface point: shadow-ray origin and next extend origin
 	f3 pn = mk(0.f, 0.f, 0.f);     // surface normal of the path (RayQueue::normal)
-	f3 pdir = mk(0.f, 0.f, 0.f);   // direction of the extend ray in flight (RayQueue::direction)
 	f3 scolor = mk(0.f, 0.f, 0.f); // ShadowQueue::color
+	f3 bdir = mk(0.f, 0.f, 0.f);   // next bounce direction, drawn in shade, used once the shadow ray is done
 
 	bool work_left = true;
 	// hang guard only (NaN directions): no wave needs more scheduler rounds than this
 	long long rounds_left = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fc.spp) + 1) * (fc.max_bounces + 2) *
 							(2ll * sc.cells + sc.cells_height + 64);
-	uint32_t runsA = 0, lanesA = 0, runsB = 0, lanesB = 0, runsC = 0, lanesC = 0; // wave-uniform scheduler statistics
+	uint32_t runsA = 0, lanesA = 0, runsB = 0, lanesB = 0, runsC = 0, lanesC = 0, runsD = 0, lanesD = 0; // wave-uniform scheduler statistics
 
 	for (;;) {
 		// ---- refill: hand pixels to idle lanes, 16 (one 4x4 chunk) at a time
@@ -479,12 +485,13 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 					const int tile_x = static_cast<int>(tile % static_cast<uint32_t>(fc.tiles_x));
 					const int tile_y = static_cast<int>(tile / static_cast<uint32_t>(fc.tiles_x));
 					const int cx = static_cast<int>((k & 1u) | ((k >> 1) & 2u)), cy = static_cast<int>(((k >> 1) & 1u) | ((k >> 2) & 2u));
-					x = tile_x * 16 + cx * 4 + (rank & 3);
+					const int x = tile_x * 16 + cx * 4 + (rank & 3);
 					const int ly = tile_y * 16 + cy * 4 + ((rank >> 2) & 3); // row inside this shard's packed buffer
-					y = ((ly / fc.band_rows) * fc.shard_count + fc.shard_rank) * fc.band_rows + ly % fc.band_rows;
+					const int y = ((ly / fc.band_rows) * fc.shard_count + fc.shard_rank) * fc.band_rows + ly % fc.band_rows;
 					if (x < fc.width && ly < fc.local_rows && y < fc.height) {
 						p = static_cast<uint32_t>(y) * W + static_cast<uint32_t>(x);
-						local_pixel = static_cast<size_t>(ly) * W + static_cast<size_t>(x);
+						local_pixel = static_cast<uint32_t>(ly) * W + static_cast<uint32_t>(x);
+						xy = static_cast<uint32_t>(x) | (static_cast<uint32_t>(y) << 16);
 						acc = accum[local_pixel];
 						s = 0;
 						pstate = P_GEN;
@@ -500,21 +507,26 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 		const int nA = __popcll(__ballot(state == ST_OUTER));
 		const int nB = __popcll(__ballot(state == ST_CAND));
 		const int nC = __popcll(__ballot(state == ST_NEED));
-		const int live = nA + nB + nC;
+		const int nD = __popcll(__ballot(state == ST_CONN));
+		const int live = nA + nB + nC + nD;
 		if (live == 0) {
 			if (!work_left || --rounds_left < 0) break;
 			continue; // everything idle but chunks remain (only pixels outside the image were handed out)
 		}
 		if (--rounds_left < 0) break;
-		// Policy: an expensive phase runs once a quarter of the live lanes wait for it (or nothing else can run);
-		// otherwise the DDA keeps moving.
-		const int quorum = (live + 3) / 4;
-		const bool runC = nC >= quorum || (nA == 0 && nB == 0);
-		const bool runA = !runC && !(nB >= quorum || nA == 0);
+		// Policy: an expensive phase runs once a quarter of the live lanes wait for it, the cheap connect phase
+		// once an eighth does; otherwise the DDA keeps moving.  With no lane left in the DDA the largest group runs.
+		const int quorum = (live + 3) / 4, quorum_conn = (live + 7) / 8;
+		int phase; // 0 = A (DDA moves), 1 = B (candidates), 2 = C (shade / generate), 3 = D (connect)
+		if (nC >= quorum) phase = 2;
+		else if (nB >= quorum) phase = 1;
+		else if (nD >= quorum_conn) phase = 3;
+		else if (nA > 0) phase = 0;
+		else phase = (nC >= nB && nC >= nD) ? 2 : (nB >= nD ? 1 : 3);
 
-		if (runC) {
+		if (phase == 2) {
 			if (DBG) { runsC++; lanesC += nC; }
-			// ================= phase C: path logic for lanes whose ray just finished (or that need their first ray)
+			// ================= phase C: shade the finished extend ray / generate the next primary ray, then set the new ray up
 			if (state == ST_NEED) {
 				bool need_setup = false;
 				f3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f);
@@ -541,22 +553,41 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 					}
 					const bool primary_only = fc.flags & 1u; // BM_FLAG_PRIMARY_ONLY
 					// direction whose sky terms are needed: the ray itself on a miss, the sun sample on a hit
-					f3 view = pdir;
+					f3 view = r.d; // RayQueue::direction of the extend ray that just finished
 					float sunLight = 0.f;
 					bool cast = false;
 					if (is_hit && !primary_only) {
 						// ---- shade, hit branch (kernel.cu:255-302); frame = base_frame + bounce, queue slot = slot.
 						// throughput is identically (1,1,1) (kernel.cu:261,271) and is not carried.
 						const uint32_t frame = fc.base_frame + static_cast<uint32_t>(bounces);
-						sseed = (frame * p * 147565741u) * 720898027u * slot;
-						hitp = hitp + pdir * r.distance;
+						const uint32_t slot = p + static_cast<uint32_t>(fc.sample_base + s) * W * H;
+						uint32_t sseed = (frame * p * 147565741u) * 720898027u * slot;
+						hitp = hitp + r.d * r.distance;
 						hitp = hitp + pn * 2.f * kEpsilon;
 						view = cone_sample(ld3(fc.sun_direction), fc.cone_extent, sseed);
 						sunLight = dot(pn, view);
 						cast = sunLight > 0.f;
 						terminated = !(bounces < fc.max_bounces);
-						if (terminated) acc.w += 1.f; // kernel.cu:301
-						if (!cast) pstate = P_BOUNCE;
+						if (terminated) {
+							acc.w += 1.f; // kernel.cu:301
+						} else {
+							// kernel.cu:281-299: cosine-weighted bounce, drawn right after the cone sample as in shade();
+							// the direction is kept in `bdir` until the shadow ray (if any) has been traced.
+							const float r1 = 2.f * kPi * random_float(sseed);
+							const float r2 = random_float(sseed);
+							const float r2s = sqrtf(r2);
+							// computeOrthonormalBasisNaive (kernel.cu:76-84)
+							f3 u = fabs(static_cast<double>(pn.x)) > .9 ? mk(0.0f, 1.0f, 0.0f) : mk(1.0f, 0.0f, 0.0f);
+							u = normalize(cross(u, pn));
+							const f3 v = cross(pn, u);
+							float sn, cs;
+							det_sincos(r1, sn, cs);
+							bdir = normalize(((u * cs) * r2s + (v * sn) * r2s) + pn * sqrtf(1 - r2));
+						}
+						if (!cast) {
+							if (terminated) { s++; pstate = P_GEN; }
+							else { bounces++; ro = hitp; rd = bdir; r.n = pn; shadow = false; need_setup = true; }
+						}
 					}
 					if (!is_hit || cast) {
 						const SkyView sv = sky_view(fc, view);
@@ -578,56 +609,20 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 						s++;
 						pstate = P_GEN;
 					}
-				} else if (pstate == P_SHD_DONE) {
-					// ---- connect (kernel.cu:328-346): runs after shade within the same reference frame
-					const bool occluded = r.hit;
-					if (DBG) {
-						tally.shadow_rays++;
-						nsh++;
-						hsh = hmix(hsh, static_cast<uint32_t>(occluded));
-						if (occluded) {
-							hsh = hmix(hsh, static_cast<uint32_t>(info.brick_id));
-							hsh = hmix(hsh, static_cast<uint32_t>(info.sub_id) | (static_cast<uint32_t>(info.level) << 12));
-						}
-					}
-					if (!occluded) { acc.x += scolor.x; acc.y += scolor.y; acc.z += scolor.z; }
-					pstate = P_BOUNCE;
-				}
-				if (pstate == P_BOUNCE) {
-					if (!terminated) { // kernel.cu:281-299: cosine-weighted bounce; the two draws follow the cone sample's
-						const float r1 = 2.f * kPi * random_float(sseed);
-						const float r2 = random_float(sseed);
-						const float r2s = sqrtf(r2);
-						// computeOrthonormalBasisNaive (kernel.cu:76-84)
-						f3 u = fabs(static_cast<double>(pn.x)) > .9 ? mk(0.0f, 1.0f, 0.0f) : mk(1.0f, 0.0f, 0.0f);
-						u = normalize(cross(u, pn));
-						const f3 v = cross(pn, u);
-						float sn, cs;
-						det_sincos(r1, sn, cs);
-						pdir = normalize(((u * cs) * r2s + (v * sn) * r2s) + pn * sqrtf(1 - r2));
-						bounces++;
-						ro = hitp; rd = pdir;
-						r.n = pn;
-						shadow = false;
-						need_setup = true;
-					} else {
-						s++;
-						pstate = P_GEN;
-					}
 				}
 				if (pstate == P_GEN) {
 					if (s >= fc.spp) {
 						// pixel finished: publish it and wait for the next one
 						accum[local_pixel] = acc;
 						if (DBG && dbg) {
-							uint32_t* d = dbg + local_pixel * 8;
+							uint32_t* d = dbg + static_cast<size_t>(local_pixel) * 8;
 							d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = hseg; d[5] = hsh; d[6] = next | (nsh << 16);
 							d[7] = tally.index_loads - loads0;
 						}
 						state = ST_IDLE;
 					} else {
 						// ---- primary_rays (kernel.cu:157-200) for queue slot `slot`, start_position 0
-						slot = p + static_cast<uint32_t>(fc.sample_base + s) * W * H;
+						const uint32_t slot = p + static_cast<uint32_t>(fc.sample_base + s) * W * H;
 						uint32_t seed = (fc.base_frame * 147565741u) * 720898027u * slot;
 						const f3 cam_right = ld3(fc.right), cam_up = ld3(fc.up), cam_dir = ld3(fc.dir), cam_o = ld3(fc.origin);
 						// Random2DStratifiedSample (kernel.cu:40-61)
@@ -635,8 +630,8 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 						const int stratumX = stratum % 4, stratumY = (stratum / 4) % 4;
 						const float jx = 0.25f * stratumX + (random_float(seed) * 0.25f);
 						const float jy = 0.25f * stratumY + (random_float(seed) * 0.25f);
-						const float ppx = static_cast<float>(static_cast<uint32_t>(x)) - jx;
-						const float ppy = static_cast<float>(static_cast<uint32_t>(y)) - jy;
+						const float ppx = static_cast<float>(xy & 0xFFFFu) - jx;
+						const float ppy = static_cast<float>(xy >> 16) - jy;
 						const float ni = (ppx / static_cast<float>(W)) - 0.5f;
 						const float nj = ((static_cast<float>(H) - ppy) / static_cast<float>(H)) - 0.5f;
 						const f3 to_focal = normalize(cam_dir + cam_right * ni + cam_up * nj);
@@ -661,12 +656,12 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 							const float plx = fc.lens_radius * lx, ply = fc.lens_radius * lyy;
 							hitp = cam_o + cam_right * plx + cam_up * ply;
 						}
-						pdir = normalize(convergence - hitp);
+						rd = normalize(convergence - hitp);
 						pn = mk(0.f, 0.f, 0.f);
 						bounces = 0;
 						terminated = false;
 						if (DBG) tally.paths++;
-						ro = hitp; rd = pdir;
+						ro = hitp;
 						r.n = pn;
 						shadow = false;
 						need_setup = true;
@@ -675,19 +670,54 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 				if (need_setup) {
 					if (shadow) r.n = mk(0.f, 0.f, 0.f); // connect passes a zeroed normal (kernel.cu:338)
 					pstate = shadow ? P_SHD_DONE : P_EXT_DONE;
-					state = ray_setup<DBG>(sc, ro, rd, r, tally);
+					const int st = ray_setup<DBG>(sc, ro, rd, r, tally);
+					state = (st == ST_NEED && shadow) ? ST_CONN : st;
 				}
 			}
-		} else if (!runA) {
+		} else if (phase == 3) {
+			if (DBG) { runsD++; lanesD += nD; }
+			// ================= phase D: connect (kernel.cu:328-346) -- runs after shade within the same reference frame --
+			// then the stored bounce ray is set up
+			if (state == ST_CONN) {
+				const bool occluded = r.hit;
+				if (DBG) {
+					tally.shadow_rays++;
+					nsh++;
+					hsh = hmix(hsh, static_cast<uint32_t>(occluded));
+					if (occluded) {
+						hsh = hmix(hsh, static_cast<uint32_t>(info.brick_id));
+						hsh = hmix(hsh, static_cast<uint32_t>(info.sub_id) | (static_cast<uint32_t>(info.level) << 12));
+					}
+				}
+				if (!occluded) { acc.x += scolor.x; acc.y += scolor.y; acc.z += scolor.z; }
+				if (terminated) {
+					s++;
+					pstate = P_GEN;
+					state = ST_NEED; // the next primary ray (or the pixel hand-back) is phase C work
+				} else {
+					bounces++;
+					r.n = pn;
+					shadow = false;
+					pstate = P_EXT_DONE;
+					state = ray_setup<DBG>(sc, hitp, bdir, r, tally);
+				}
+			}
+		} else if (phase == 1) {
 			if (DBG) { runsB++; lanesB += nB; }
 			// ================= phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask DDA, streaming request)
-			if (state == ST_CAND) state = process_candidate<DBG>(sc, fc.campos, r, info, tally);
+			if (state == ST_CAND) {
+				const int st = process_candidate<DBG>(sc, fc.campos, r, info, tally);
+				state = (st == ST_NEED && shadow) ? ST_CONN : st;
+			}
 		} else {
 			// ================= phase A: brick-grid DDA moves; lanes that reach a non-empty cell or leave the grid wait
 #pragma unroll 1
-			for (int k = 0; k < 4; ++k) {
+			for (int k = 0; k < BM_STEPS_PER_ROUND; ++k) {
 				if (DBG) { runsA++; lanesA += __popcll(__ballot(state == ST_OUTER)); }
-				if (state == ST_OUTER) state = outer_step<DBG>(sc, r, tally);
+				if (state == ST_OUTER) {
+					const int st = outer_step<DBG>(sc, r, tally);
+					state = (st == ST_NEED && shadow) ? ST_CONN : st;
+				}
 			}
 		}
 	}
@@ -701,8 +731,8 @@ __global__ __launch_bounds__(256) void trace_paths(const DeviceScene sc, const F
 			if (lane == 0 && t) atomicAdd(&counters->v[k], t);
 		}
 		if (lane == 0) {
-			const unsigned long long st[7] = {runsA, lanesA, runsB, lanesB, runsC, lanesC, 1ull};
-			for (int k = 0; k < 7; ++k) atomicAdd(&counters->sched[k], st[k]);
+			const unsigned long long st[8] = {runsA, lanesA, runsB, lanesB, runsC, lanesC, runsD, lanesD};
+			for (int k = 0; k < 8; ++k) atomicAdd(&counters->sched[k], st[k]);
 		}
 	}
 }

@@ -91,8 +91,8 @@ typedef struct bm_counters {
 typedef struct bm_sched_stats {
 	uint64_t step_runs, step_lanes;           /* phase A: brick-grid DDA moves       */
 	uint64_t candidate_runs, candidate_lanes; /* phase B: index word + bitmask DDA   */
-	uint64_t shade_runs, shade_lanes;         /* phase C: shade / connect / next ray */
-	uint64_t waves, reserved;
+	uint64_t shade_runs, shade_lanes;         /* phase C: shade / next primary ray   */
+	uint64_t connect_runs, connect_lanes;     /* phase D: connect + bounce ray setup */
 } bm_sched_stats;
 
 /* ---- errors (replaces assert_cuda.h:5 / assert_cuda.cpp:3-13) */

@@ -16,6 +16,6 @@ scene.counters_reset()
 scene.render(cam, bm.FrameParams(W, H, spp=spp, max_bounces=3, flags=bm.BM_FLAG_COUNTERS), acc)
 c = scene.counters(); s = scene.sched_stats()
 print(c)
-for k in ("step", "candidate", "shade"):
+for k in ("step", "candidate", "shade", "connect"):
     r, l = s[k+"_runs"], s[k+"_lanes"]
-    print("%-10s runs/wave %8.1f  avg active lanes %5.1f" % (k, r/s["waves"], l/max(r,1)))
+    print("%-10s runs %10d  avg active lanes %5.1f" % (k, r, l/max(r,1)))
