@@ -157,7 +157,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (SimplexNoise terrain generated on the CPU, canonical xorshift RNG, random-free weights n/a)",
+        "data": "synthetic (SimplexNoise terrain built on the CPU by the product generator; canonical xorshift RNG streams)",
         "config": {
             "workload": f"BASELINE {args.workload}: {W}x{H}, {spp} spp per GPU-step (x{world} ranks = {spp_step} spp), "
                         f"{segments} segments/path, {n_super}^3 superchunks ({G}^3 voxels), "
@@ -175,7 +175,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
-            "traffic": None,
+            "traffic": pmc_traffic(args.workload),
             "kernel": "bm::trace_paths<false>",
             "kernel_ms_avg": round(float(np.mean(kernel_ms)), 4),
             "algorithmic_bytes_per_launch": alg_bytes / args.steps,
@@ -192,25 +192,41 @@ def main():
 
 
 def cpu_baseline(W, H, spp, max_bounces, G, cam):
-    """The oracle's scalar C port of the same per-pixel path (oracle/oracle.c orc_render), all host
-    cores, on a bounded sample of the same workload: every 4th 16-row band of the same frame."""
+    """The oracle's scalar C port of the same per-pixel path (oracle/oracle.c orc_render) on all host cores.
+    Sample: whole frames of the same workload -- one calibration frame, then enough samples per pixel for
+    roughly 3 s of wall time (tens of CPU-seconds on a many-core host)."""
     import oracle
     cores = os.cpu_count() or 1
     world = oracle.World(G, G, threads=cores)
     world.reset_device(True)
     ocam = oracle.make_camera(cam.position, cam.direction)
-    frame = oracle.make_frame(W, H, spp=spp, max_bounces=max_bounces)
-    _, _, cnt, secs = world.render(ocam, frame, want_dbg=False, threads=cores)
-    rows = H
-    nominal = W * rows * spp * (max_bounces + 1)
+    _, _, _, t1 = world.render(ocam, oracle.make_frame(W, H, spp=1, max_bounces=max_bounces), want_dbg=False, threads=cores)
+    n = max(1, min(64, int(3.0 / max(t1, 1e-3))))
+    _, _, cnt, secs = world.render(ocam, oracle.make_frame(W, H, spp=n, max_bounces=max_bounces, sample_base=1), want_dbg=False, threads=cores)
+    nominal = W * H * n * (max_bounces + 1)
     return {
         "value": round(nominal / secs / 1e6, 4),
         "unit": "Mrays/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"one full {W}x{H} frame of the same workload, sample 0 ({nominal} nominal rays, "
-                  f"{cnt['extend_rays'] + cnt['shadow_rays']} actual) in {secs:.2f} s",
+        "sample": f"{n} samples/pixel of the same {W}x{H} frame ({nominal} nominal rays, "
+                  f"{cnt['extend_rays'] + cnt['shadow_rays']} actual) in {secs:.2f} s on {cores} threads",
     }
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of this workload (separate --pmc passes,
+    tools/pmc.sh), or None.  FETCH_SIZE / WRITE_SIZE are in KiB; the gfx950 x2 correction of the guide applies to
+    wide coalesced streams only and is NOT applied here (this kernel issues 4-16 B gathers): see DESIGN.md."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("workload") != workload:
+            return None
+        return int((d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024)
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 if __name__ == "__main__":

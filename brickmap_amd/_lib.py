@@ -56,7 +56,8 @@ class bm_counters(C.Structure):
         return {n: int(getattr(self, n)) for n in COUNTER_NAMES}
 
 
-SCHED_NAMES = ("step_runs", "step_lanes", "candidate_runs", "candidate_lanes", "shade_runs", "shade_lanes", "connect_runs", "connect_lanes")
+SCHED_NAMES = ("step_runs", "step_lanes", "candidate_runs", "candidate_lanes", "shade_runs", "shade_lanes", "connect_runs", "connect_lanes",
+               "step_cycles", "candidate_cycles", "shade_cycles", "connect_cycles", "total_cycles", "reserved0", "reserved1", "waves")
 
 
 class bm_sched_stats(C.Structure):

@@ -54,6 +54,8 @@ struct FrameConstants {
 	float sun_direction[3];
 	float sun_angular_cos; // cos(1.5 deg), kernel.cu:374
 	float cone_extent;     // 1 - sun_angular_cos, kernel.cu:274
+	// view-independent head of getConeSample(sunDirection, ...) (sunsky.cu:172-174): normalize(dir), o1, o2
+	float cone_dir[3], cone_o1[3], cone_o2[3];
 	float sunE;            // SunIntensity(dot(sunDirection, up))
 	float rayleigh[3];     // rayleighAtX
 	float mie[3];          // mieAtX = totalMie(...) * mieCoefficient
@@ -72,6 +74,7 @@ struct FrameConstants {
 struct DeviceCounters { // v: same order as bm_counters; sched: same order as bm_sched_stats
 	unsigned long long v[8];
 	unsigned long long sched[8];
+	unsigned long long cycles[8]; // s_memtime ticks per scheduler phase, summed over waves: A, B, C, D, total, 0, 0, waves
 };
 
 } // namespace bm

@@ -73,6 +73,15 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp,
 	const float px = (fp->sun_position[0] - 0.0f) * 6.28f, py = (fp->sun_position[1] - 0.5f) * 3.14f;
 	const V3 sun = normalize3(V3{std::cos(px) * std::sin(py), std::sin(px) * std::sin(py), std::cos(py)});
 	fc->sun_direction[0] = sun.x; fc->sun_direction[1] = sun.y; fc->sun_direction[2] = sun.z;
+	{ // getConeSample's frame around the sun direction (sunsky.cu:163-174), same fp32 operations as the reference
+		const V3 cd = normalize3(sun);
+		const V3 ortho = std::fabs(cd.x) > std::fabs(cd.z) ? V3{-cd.y, cd.x, 0.0f} : V3{0.0f, -cd.z, cd.y};
+		const V3 o1 = normalize3(ortho);
+		const V3 o2 = normalize3(cross3(cd, o1));
+		fc->cone_dir[0] = cd.x; fc->cone_dir[1] = cd.y; fc->cone_dir[2] = cd.z;
+		fc->cone_o1[0] = o1.x; fc->cone_o1[1] = o1.y; fc->cone_o1[2] = o1.z;
+		fc->cone_o2[0] = o2.x; fc->cone_o2[1] = o2.y; fc->cone_o2[2] = o2.z;
+	}
 	const V3 sky_up{0.0f, 0.0f, 1.0f};
 	fc->sunE = sun_intensity(dot3(sun, sky_up));
 	const float rayleigh[3] = {5.176821E-6f, 1.2785348E-5f, 2.8530756E-5f};
@@ -451,7 +460,7 @@ int Scene::sched_stats_read(bm_sched_stats* out) {
 	if (!out) { set_error("null argument"); return BM_EINVAL; }
 	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipDeviceSynchronize());
-	static_assert(sizeof(bm_sched_stats) == sizeof(DeviceCounters::sched), "scheduler stat blocks must match");
+	static_assert(sizeof(bm_sched_stats) == sizeof(DeviceCounters::sched) + sizeof(DeviceCounters::cycles), "scheduler stat blocks must match");
 	BM_HIP(hipMemcpy(out, reinterpret_cast<const char*>(d_counters_) + offsetof(DeviceCounters, sched), sizeof(bm_sched_stats), hipMemcpyDeviceToHost));
 	return 0;
 }

@@ -69,15 +69,37 @@ struct HitInfo {
 };
 
 // ---- 8^3 bitmask DDA (voxel.cuh:79-133) and 2^3 LoD DDA (voxel.cuh:26-77): one body, N = 8 or 2.
-// `words` points at the 16-word brick (N == 8); `byte` is the LoD mask from the index word (N == 2).
+// `words` points at the 64-byte brick (N == 8); `byte` is the LoD mask from the index word (N == 2).
+// The brick is fetched once, as four 16-byte loads in flight together, and walked from registers: a
+// z-slice of the brick is exactly one 64-bit word (bit x + 8y), re-selected only when the walk changes z.
+struct BrickRegs {
+	uint4 q0, q1, q2, q3;
+};
+__device__ __forceinline__ unsigned long long brick_slice(const BrickRegs& b, int z) {
+	// binary select tree on the three bits of z (14 v_cndmask, no memory access)
+	const bool b0 = z & 1, b1 = z & 2, b2 = z & 4;
+	const uint32_t a0l = b0 ? b.q0.z : b.q0.x, a0h = b0 ? b.q0.w : b.q0.y;
+	const uint32_t a1l = b0 ? b.q1.z : b.q1.x, a1h = b0 ? b.q1.w : b.q1.y;
+	const uint32_t a2l = b0 ? b.q2.z : b.q2.x, a2h = b0 ? b.q2.w : b.q2.y;
+	const uint32_t a3l = b0 ? b.q3.z : b.q3.x, a3h = b0 ? b.q3.w : b.q3.y;
+	const uint32_t c0l = b1 ? a1l : a0l, c0h = b1 ? a1h : a0h;
+	const uint32_t c1l = b1 ? a3l : a2l, c1h = b1 ? a3h : a2h;
+	const uint32_t lo = b2 ? c1l : c0l, hi = b2 ? c1h : c0h;
+	return static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32);
+}
+
 template <int N, bool DBG>
 __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, f3& normal, float& distance, const uint32_t* __restrict__ words,
 											   uint32_t byte, int& sub_id, Tally& tally) {
+	BrickRegs brick;
+	if (N == 8) { // issue the whole 64-byte read before the set-up arithmetic below
+		const uint4* q = reinterpret_cast<const uint4*>(words);
+		brick.q0 = q[0]; brick.q1 = q[1]; brick.q2 = q[2]; brick.q3 = q[3];
+	}
 	int px = static_cast<int>(origin.x), py = static_cast<int>(origin.y), pz = static_cast<int>(origin.z);
 	const float cbx = dir.x > 0.f ? static_cast<float>(px + 1) : static_cast<float>(px);
 	const float cby = dir.y > 0.f ? static_cast<float>(py + 1) : static_cast<float>(py);
 	const float cbz = dir.z > 0.f ? static_cast<float>(pz + 1) : static_cast<float>(pz);
-	const int outx = dir.x > 0.f ? N : -1, outy = dir.y > 0.f ? N : -1, outz = dir.z > 0.f ? N : -1;
 	const int sx = isign(dir.x), sy = isign(dir.y), sz = isign(dir.z);
 	const float rx = dir.x == 0.0f ? 0.0f : 1.f / dir.x;
 	const float ry = dir.y == 0.0f ? 0.0f : 1.f / dir.y;
@@ -89,13 +111,14 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, f3& normal, fl
 	px %= N; py %= N; pz %= N;
 	distance = 0.f;
 	int axis = -1;
+	// "& 7" / "& 63" only define what the reference leaves undefined (a negative start cell); no effect otherwise
+	unsigned long long slice = N == 8 ? brick_slice(brick, pz & 7) : 0ull;
 	// at most 3N-2 cells lie on a line through an N^3 block; the bound only guards against NaN input
 	for (int guard = 0; guard < 3 * N + 2; ++guard) {
 		if (DBG) tally.voxel_steps++;
-		const int b = px + py * N + pz * N * N;
 		bool solid;
-		if (N == 8) solid = (words[(b >> 5) & 15] >> (b & 31)) & 1u;
-		else solid = (byte >> (b & 31)) & 1u;
+		if (N == 8) solid = (slice >> ((px + py * 8) & 63)) & 1ull;
+		else solid = (byte >> ((px + py * 2 + pz * 4) & 31)) & 1u;
 		if (solid) {
 			if (axis > -1) {
 				normal = mk(0.f, 0.f, 0.f);
@@ -103,15 +126,24 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, f3& normal, fl
 				else if (axis == 1) { normal.y = -static_cast<float>(sy); distance = ty - dy; }
 				else { normal.z = -static_cast<float>(sz); distance = tz - dz; }
 			}
-			sub_id = b;
+			sub_id = px + py * N + pz * N * N;
 			return true;
 		}
+		// select-style move (voxel.cuh:122-130); `t += mask ? delta : 0` is `tmax += mask * tdelta` for finite deltas
 		const bool mx = tx < ty && tx < tz;
-		const bool my = !mx && ty <= tx && ty < tz;
-		axis = (tx < ty) ? ((tx < tz) ? 0 : 2) : ((ty < tz) ? 1 : 2);
-		if (mx) { px += sx; if (px == outx) break; tx += dx; }
-		else if (my) { py += sy; if (py == outy) break; ty += dy; }
-		else { pz += sz; if (pz == outz) break; tz += dz; }
+		const bool my = ty <= tx && ty < tz; // mx implies !my
+		const bool mz = !(mx || my);
+		axis = mx ? 0 : (my ? 1 : 2);
+		px += mx ? sx : 0;
+		py += my ? sy : 0;
+		pz += mz ? sz : 0;
+		const int c = mx ? px : (my ? py : pz);
+		const int s_sel = mx ? sx : (my ? sy : sz);
+		if (c == (s_sel > 0 ? N : -1)) break; // left the block
+		tx += mx ? dx : 0.f;
+		ty += my ? dy : 0.f;
+		tz += mz ? dz : 0.f;
+		if (N == 8 && mz) slice = brick_slice(brick, pz);
 	}
 	return false;
 }
@@ -368,16 +400,14 @@ __device__ __forceinline__ f3 sunsky_radiance(const FrameConstants& fc, f3 viewD
 	return sunsky_from_view(fc, sky_view(fc, viewDir));
 }
 
-// getConeSample (sunsky.cu:163-183)
-__device__ __forceinline__ f3 cone_sample(f3 dir, float extent, uint32_t& seed) {
-	dir = normalize(dir);
-	const f3 o = fabsf(dir.x) > fabsf(dir.z) ? mk(-dir.y, dir.x, 0.0f) : mk(0.0f, -dir.z, dir.y);
-	const f3 o1 = normalize(o);
-	const f3 o2 = normalize(cross(dir, o1));
+// getConeSample(sunDirection, extent, seed) (sunsky.cu:163-183).  Its orthonormal frame depends only on the
+// sun direction, so normalize(dir), o1 and o2 arrive precomputed (same fp32 operations, done once on the host).
+__device__ __forceinline__ f3 cone_sample(const FrameConstants& fc, uint32_t& seed) {
+	const f3 dir = ld3(fc.cone_dir), o1 = ld3(fc.cone_o1), o2 = ld3(fc.cone_o2);
 	float rx = random_float2(seed);
 	float ry = random_float2(seed);
 	rx = rx * 2.f * kPi;
-	ry = 1.0f - ry * extent;
+	ry = 1.0f - ry * fc.cone_extent;
 	const float oneminus = sqrtf(1.0f - ry * ry);
 	float s, c;
 	det_sincos(rx, s, c);
@@ -467,6 +497,9 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 							(2ll * sc.cells + sc.cells_height + 64);
 	uint32_t runsA = 0, lanesA = 0, runsB = 0, lanesB = 0, runsC = 0, lanesC = 0, runsD = 0, lanesD = 0; // wave-uniform scheduler statistics
 
+	unsigned long long cycA = 0, cycB = 0, cycC = 0, cycD = 0;
+	const unsigned long long t_begin = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
+
 	for (;;) {
 		// ---- refill: hand pixels to idle lanes, 16 (one 4x4 chunk) at a time
 		const unsigned long long idle = __ballot(state == ST_IDLE);
@@ -524,6 +557,7 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 		else if (nA > 0) phase = 0;
 		else phase = (nC >= nB && nC >= nD) ? 2 : (nB >= nD ? 1 : 3);
 
+		const unsigned long long t_phase = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
 		if (phase == 2) {
 			if (DBG) { runsC++; lanesC += nC; }
 			// ================= phase C: shade the finished extend ray / generate the next primary ray, then set the new ray up
@@ -564,7 +598,7 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 						uint32_t sseed = (frame * p * 147565741u) * 720898027u * slot;
 						hitp = hitp + r.d * r.distance;
 						hitp = hitp + pn * 2.f * kEpsilon;
-						view = cone_sample(ld3(fc.sun_direction), fc.cone_extent, sseed);
+						view = cone_sample(fc, sseed);
 						sunLight = dot(pn, view);
 						cast = sunLight > 0.f;
 						terminated = !(bounces < fc.max_bounces);
@@ -720,6 +754,10 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 				}
 			}
 		}
+		if (DBG) {
+			const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_phase;
+			if (phase == 0) cycA += dt; else if (phase == 1) cycB += dt; else if (phase == 2) cycC += dt; else cycD += dt;
+		}
 	}
 
 	if (DBG && counters) { // wave-level sum, one atomic per wave and counter
@@ -733,6 +771,8 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 		if (lane == 0) {
 			const unsigned long long st[8] = {runsA, lanesA, runsB, lanesB, runsC, lanesC, runsD, lanesD};
 			for (int k = 0; k < 8; ++k) atomicAdd(&counters->sched[k], st[k]);
+			const unsigned long long cy[8] = {cycA, cycB, cycC, cycD, __builtin_amdgcn_s_memtime() - t_begin, 0ull, 0ull, 1ull};
+			for (int k = 0; k < 8; ++k) atomicAdd(&counters->cycles[k], cy[k]);
 		}
 	}
 }

@@ -1,0 +1,146 @@
+// brickmap.hpp -- header-only C++ mirror of the reference's host interface for the path-trace hot path,
+// on top of the C-ABI in brickmap.h.  Same names, argument meaning and error behaviour as the reference
+// (file:line into the reference's src/):
+//   Camera          camera.h:3-24, camera.cpp:48-54          (input handling needs a window: out of scope)
+//   State           state.h:5-34                             (ray queues / GL interop are gone: paths live in registers)
+//   Scene           Scene.h:7-44, Scene.cpp:29-258
+//   launch_kernels  launch.h:6, kernel.cu:366-439
+//   hip(...)        assert_cuda.h:5, assert_cuda.cpp:3-13     (print, then exit(code): the reference's cuda() macro)
+// A maintainer swaps `#include "launch.h"` + the CUDA sources for this header and links libbrickmap_hip.so;
+// see INTEGRATION.md for the exact diff against src/main.cpp.
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+
+#include "brickmap.h"
+
+namespace brickmap {
+
+// assert_cuda.cpp:3-13: report and abort on any device error (the C-ABI itself only returns codes)
+inline int bm_assert(int code, const char* file, int line, bool abort = true) {
+	if (code != 0) {
+		std::fprintf(stderr, "hip_assert: %s %s %d\n", bm_last_error_string(), file, line);
+		if (abort) std::exit(code);
+	}
+	return code;
+}
+#define BM_CHECKED(call) ::brickmap::bm_assert((call), __FILE__, __LINE__, true)
+
+struct vec2 { float x, y; };
+struct vec3 { float x, y, z; };
+struct vec4 { float x, y, z, w; };
+
+// variables.h:37-38, variables.cpp:3-4
+inline vec2 sun_position = {0.05f, 0.1f};
+inline bool sun_position_changed = true;
+
+struct Camera { // camera.h:3-24
+	vec3 position = {512, 512, 300};
+	vec3 direction = {1, 0, 0};
+	vec3 up = {0, 0, 1};
+	float focalDistance = 1;
+	float lensRadius = 0.0f;
+	double horizontal_angle = 0.0;
+	double vertical_angle = 0.0;
+
+	void update() { // camera.cpp:48-54
+		vec3 d = {static_cast<float>(std::cos(vertical_angle) * std::sin(horizontal_angle)),
+				  static_cast<float>(std::cos(vertical_angle) * std::cos(horizontal_angle)), static_cast<float>(std::sin(vertical_angle))};
+		const float inv = 1.0f / std::sqrt((d.x * d.x + d.y * d.y) + d.z * d.z); // glm::normalize
+		direction = {d.x * inv, d.y * inv, d.z * inv};
+	}
+};
+inline Camera camera; // camera.h:24 `extern Camera camera;`
+
+class Scene { // Scene.h:7-44
+public:
+	struct GPUScene { // passed by value to launch_kernels, like Scene::GPUScene (Scene.h:9-17)
+		bm_scene* handle = nullptr;
+	};
+	GPUScene gpuScene;
+
+	// world dimensions are constexpr in the reference (variables.h:7-8: 4096 x 4096 x 512 voxels)
+	explicit Scene(int grid_size = 4096, int grid_height = 512, int device = 0) { BM_CHECKED(bm_scene_create(device, grid_size, grid_height, &gpuScene.handle)); }
+	~Scene() { bm_scene_destroy(gpuScene.handle); }
+	Scene(const Scene&) = delete;
+	Scene& operator=(const Scene&) = delete;
+
+	void generate_supercell(int start_x, int start_y, int start_z) { BM_CHECKED(bm_scene_generate_supercell(gpuScene.handle, start_x, start_y, start_z)); }
+	void generate() { BM_CHECKED(bm_scene_generate(gpuScene.handle, static_cast<int>(std::thread::hardware_concurrency()))); }
+	void process_load_queue() { BM_CHECKED(bm_scene_process_load_queue(gpuScene.handle, nullptr)); }
+	void dump() { BM_CHECKED(bm_scene_dump(gpuScene.handle, "dump.txt")); }
+	// BASELINE configs 1-2: everything resident up front (no counterpart in the reference)
+	void preload_all() { BM_CHECKED(bm_scene_preload_all(gpuScene.handle)); }
+};
+
+struct State { // state.h:5-34 without the wavefront queues and the GL interop
+	vec4* blit_buffer = nullptr; // device memory, float4 per pixel: rgb = radiance sum, a = terminated paths
+	size_t screen_width, screen_height;
+	int device;
+
+	State(size_t width, size_t height, int device_ = 0) : screen_width(width), screen_height(height), device(device_) { alloc(); }
+	~State() { bm_buffer_free(device, blit_buffer); }
+	void screen_resize(size_t width, size_t height) {
+		screen_width = width;
+		screen_height = height;
+		BM_CHECKED(bm_buffer_free(device, blit_buffer));
+		alloc();
+	}
+
+private:
+	void alloc() {
+		void* p = nullptr;
+		BM_CHECKED(bm_buffer_alloc(device, screen_width * screen_height * sizeof(vec4), &p));
+		BM_CHECKED(bm_buffer_zero(device, p, screen_width * screen_height * sizeof(vec4), nullptr));
+		blit_buffer = static_cast<vec4*>(p);
+	}
+};
+
+// launch_kernels (launch.h:6, kernel.cu:366-439).  The cudaSurfaceObject_t and the three queue pointers of the
+// reference signature are gone (no GL surface; paths live in registers); `spp` complete paths per pixel are
+// traced per call instead of one bounce of every in-flight path.  As in the reference the call blocks until
+// the frame is done (kernel.cu:431) and a camera / sun change resets the accumulation (kernel.cu:387-403).
+inline int launch_kernels(State& state, vec4* blit_buffer, Scene::GPUScene gpuScene, int spp = 1, int max_bounces = 3) {
+	static bool first_time = true;
+	static int sample_base = 0;
+	static Camera last;
+	bool reset_buffer = first_time || last.position.x != camera.position.x || last.position.y != camera.position.y ||
+						last.position.z != camera.position.z || last.direction.x != camera.direction.x || last.direction.y != camera.direction.y ||
+						last.direction.z != camera.direction.z || last.focalDistance != camera.focalDistance || last.lensRadius != camera.lensRadius;
+	first_time = false;
+	if (sun_position_changed) {
+		sun_position_changed = false;
+		reset_buffer = true;
+	}
+	if (reset_buffer) {
+		BM_CHECKED(bm_buffer_zero(state.device, blit_buffer, state.screen_width * state.screen_height * sizeof(vec4), nullptr));
+		sample_base = 0;
+	}
+	bm_camera cam{};
+	cam.position[0] = camera.position.x; cam.position[1] = camera.position.y; cam.position[2] = camera.position.z;
+	cam.direction[0] = camera.direction.x; cam.direction[1] = camera.direction.y; cam.direction[2] = camera.direction.z;
+	cam.up[0] = camera.up.x; cam.up[1] = camera.up.y; cam.up[2] = camera.up.z;
+	cam.focal_distance = camera.focalDistance;
+	cam.lens_radius = camera.lensRadius;
+	bm_frame_params fp{};
+	fp.width = static_cast<int32_t>(state.screen_width);
+	fp.height = static_cast<int32_t>(state.screen_height);
+	fp.spp = spp;
+	fp.sample_base = sample_base;
+	fp.max_bounces = max_bounces;
+	fp.base_frame = 1;
+	fp.band_rows = fp.height;
+	fp.shard_rank = 0;
+	fp.shard_count = 1;
+	fp.sun_position[0] = sun_position.x;
+	fp.sun_position[1] = sun_position.y;
+	BM_CHECKED(bm_render_frame(gpuScene.handle, &cam, &fp, reinterpret_cast<float*>(blit_buffer), nullptr, nullptr));
+	BM_CHECKED(bm_synchronize(gpuScene.handle));
+	sample_base += spp;
+	last = camera;
+	return 0; // the reference always returns cudaSuccess (kernel.cu:438)
+}
+
+} // namespace brickmap

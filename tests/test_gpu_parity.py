@@ -359,3 +359,30 @@ def test_errors_are_reported_not_fatal(bm, torch_cuda):
     with pytest.raises(bm.BrickmapError):
         s.preload_all()  # not generated yet
     s.close()
+
+
+def test_cpp_headless_example_streams_and_renders(bm, torch_cuda, tmp_path):
+    """The C++ mirror (include/brickmap.hpp) driven like the reference's main loop: generate, then
+    launch_kernels + process_load_queue per frame with on-demand brick streaming, resolve, write a PPM."""
+    import subprocess
+    from conftest import ROOT
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
+    out = tmp_path / "frame.ppm"
+    r = subprocess.run([os.path.join(ROOT, "examples", "headless_main"), "256", "256", "160", "96", "24", str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bricks resident" in r.stdout
+    data = out.read_bytes()
+    assert data.startswith(b"P6\n160 96\n255\n") and len(data) == len(b"P6\n160 96\n255\n") + 160 * 96 * 3
+    px = np.frombuffer(data[len(b"P6\n160 96\n255\n"):], np.uint8)
+    assert px.max() > 0 and len(np.unique(px)) > 16  # an actual image, not a constant
+
+
+def test_scheduler_statistics(bm, orc, torch_cuda, scene256):
+    cam, _ = cameras(bm, orc, 256)
+    scene256.counters_reset()
+    gpu_render(bm, torch_cuda, scene256, cam, bm.FrameParams(128, 96, spp=2, max_bounces=3, flags=bm.BM_FLAG_COUNTERS), want_dbg=False)
+    c, s = scene256.counters(), scene256.sched_stats()
+    assert s["step_lanes"] + c["extend_rays"] + c["shadow_rays"] >= c["index_loads"]  # every visited cell is a move or a ray start
+    assert s["candidate_lanes"] >= c["brick_tests"] and s["shade_lanes"] >= c["extend_rays"] and s["connect_lanes"] == c["shadow_rays"]
+    assert 0 < s["step_lanes"] <= 64 * s["step_runs"] and s["waves"] > 0

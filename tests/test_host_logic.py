@@ -87,3 +87,12 @@ def test_no_reference_reads_at_runtime():
     """/root/reference does not exist on the GPU box: product, bench and smoke never open it."""
     for rel in ["bench.py", "__graft_entry__.py", "brickmap_amd/_lib.py", "brickmap_amd/host.py", "brickmap_amd/dist.py"]:
         assert "/root/reference" not in open(os.path.join(ROOT, rel)).read(), rel
+
+
+def test_cpp_mirror_example_builds():
+    """include/brickmap.hpp + examples/headless_main.cpp (the reference-shaped C++ driver) compile and link
+    against the in-tree library with plain g++ (no device needed to build)."""
+    import subprocess
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "examples")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.exists(os.path.join(ROOT, "examples", "headless_main"))

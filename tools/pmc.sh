@@ -22,4 +22,6 @@ for f in glob.glob("$OUT/p*/p_counter_collection.csv"):
         tot[r["Counter_Name"]]["v"] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 disp = 4
 for c in sorted(tot): print(c, tot[c]["v"] / disp)
+import json
+json.dump({"workload": "config2", "per": "launch of bm::trace_paths<false>", **{("%s_KiB" % c if c in ("FETCH_SIZE", "WRITE_SIZE") else c): tot[c]["v"] / disp for c in sorted(tot)}}, open("$OUT/pmc_summary.json", "w"), indent=1)
 PY

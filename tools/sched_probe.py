@@ -18,4 +18,6 @@ c = scene.counters(); s = scene.sched_stats()
 print(c)
 for k in ("step", "candidate", "shade", "connect"):
     r, l = s[k+"_runs"], s[k+"_lanes"]
-    print("%-10s runs %10d  avg active lanes %5.1f" % (k, r, l/max(r,1)))
+    cy = s[k+"_cycles"]
+    print("%-10s runs %10d  avg active lanes %5.1f   cycles/run %8.1f   share of wave time %5.1f%%" % (k, r, l/max(r,1), cy/max(r,1), 100.0*cy/s["total_cycles"]))
+print("waves", s["waves"], "avg wave cycles", s["total_cycles"]/s["waves"])
