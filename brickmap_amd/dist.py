@@ -11,6 +11,7 @@ link per peer into the root).  No collective sits on the data path of the render
 import numpy as np
 
 DEFAULT_BAND_ROWS = 16  # one row of 16x16 tiles
+_cache = {}  # receive buffers / row indices, keyed by the gather's shape (per-frame gathers reuse them)
 
 
 def shard_rows(height, band_rows, rank, world):
@@ -36,19 +37,25 @@ def gather_frame(local, height, band_rows, group=None, dst=0):
     counts = [len(shard_rows(height, band_rows, r, world)) for r in range(world)]
     assert local.shape[0] == counts[rank], f"rank {rank}: {local.shape[0]} local rows, expected {counts[rank]}"
     max_rows = max(counts)
+    out_device = local.device
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()  # test-only path: gloo has no device gather; RCCL ("nccl") gathers device buffers directly
     if local.shape[0] != max_rows:
         pad = torch.zeros((max_rows - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         send = torch.cat([local, pad], dim=0)
     else:
         send = local.contiguous()
     if rank == dst:
-        recv = [torch.empty_like(send) for _ in range(world)]
+        key = (tuple(send.shape), send.dtype, str(send.device), height, band_rows, world)
+        if key not in _cache:
+            _cache[key] = ([torch.empty_like(send) for _ in range(world)],
+                           [torch.as_tensor(shard_rows(height, band_rows, r, world), device=local.device, dtype=torch.long) for r in range(world)],
+                           torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device))
+        recv, row_index, out = _cache[key]
         dist.gather(send, gather_list=recv, dst=dst, group=group)
-        out = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         for r in range(world):
-            rows = torch.as_tensor(shard_rows(height, band_rows, r, world), device=local.device, dtype=torch.long)
-            if rows.numel():
-                out.index_copy_(0, rows, recv[r][: counts[r]])
-        return out
+            if row_index[r].numel():
+                out.index_copy_(0, row_index[r], recv[r][: counts[r]])
+        return out.to(out_device)
     dist.gather(send, gather_list=None, dst=dst, group=group)
     return None
