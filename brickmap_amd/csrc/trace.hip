@@ -88,9 +88,11 @@ __device__ __forceinline__ unsigned long long brick_slice(const BrickRegs& b, in
 	return static_cast<unsigned long long>(lo) | (static_cast<unsigned long long>(hi) << 32);
 }
 
+// `steps` / `deltas` are the brick-grid walk's step signs and tdelta = |1/d|: the reference recomputes
+// sign(d) and 1/d here (voxel.cuh:90-101) from the same direction, i.e. the very same values.
 template <int N, bool DBG>
-__device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, f3& normal, float& distance, const uint32_t* __restrict__ words,
-											   uint32_t byte, int& sub_id, Tally& tally) {
+__device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy, int sz, float dx, float dy, float dz, f3& normal, float& distance,
+											   const uint32_t* __restrict__ words, uint32_t byte, int& sub_id, Tally& tally) {
 	BrickRegs brick;
 	if (N == 8) { // issue the whole 64-byte read before the set-up arithmetic below
 		const uint4* q = reinterpret_cast<const uint4*>(words);
@@ -100,14 +102,11 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, f3& normal, fl
 	const float cbx = dir.x > 0.f ? static_cast<float>(px + 1) : static_cast<float>(px);
 	const float cby = dir.y > 0.f ? static_cast<float>(py + 1) : static_cast<float>(py);
 	const float cbz = dir.z > 0.f ? static_cast<float>(pz + 1) : static_cast<float>(pz);
-	const int sx = isign(dir.x), sy = isign(dir.y), sz = isign(dir.z);
-	const float rx = dir.x == 0.0f ? 0.0f : 1.f / dir.x;
-	const float ry = dir.y == 0.0f ? 0.0f : 1.f / dir.y;
-	const float rz = dir.z == 0.0f ? 0.0f : 1.f / dir.z;
+	// rdinv = sign * |1/d| exactly (0 for d == 0)
+	const float rx = static_cast<float>(sx) * dx, ry = static_cast<float>(sy) * dy, rz = static_cast<float>(sz) * dz;
 	float tx = dir.x != 0.f ? (cbx - origin.x) * rx : 1000000.f;
 	float ty = dir.y != 0.f ? (cby - origin.y) * ry : 1000000.f;
 	float tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
-	const float dx = static_cast<float>(sx) * rx, dy = static_cast<float>(sy) * ry, dz = static_cast<float>(sz) * rz;
 	px %= N; py %= N; pz %= N;
 	distance = 0.f;
 	int axis = -1;
@@ -197,13 +196,20 @@ template <bool DBG>
 __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const f3 dir, RayState& r, Tally& tally) {
 	r.hit = false;
 	r.d = dir;
-	// intersect_aabb_branchless2 (voxel.cuh:13-24)
-	const f3 t1 = (mk(0.f, 0.f, 0.f) - origin) / dir;
-	const f3 t2 = (mk(sc.grid_size_f, sc.grid_size_f, sc.grid_height_f) - origin) / dir;
-	const f3 tMin = mk(gmin(t1.x, t2.x), gmin(t1.y, t2.y), gmin(t1.z, t2.z));
-	const f3 tMax = mk(gmax(t1.x, t2.x), gmax(t1.y, t2.y), gmax(t1.z, t2.z));
-	const float tminn = gmax(gmax(tMin.x, 0.f), gmax(tMin.y, tMin.z));
-	if (!(gmin(tMax.x, gmin(tMax.y, tMax.z)) > tminn)) return ST_NEED;
+	// intersect_aabb_branchless2 (voxel.cuh:13-24).  For an origin strictly inside the box every slab entry time is
+	// negative and every exit time positive, so the reference's result is exactly (true, tmin = 0): the six IEEE
+	// divisions are only needed for rays that start on or outside the boundary.
+	float tminn = 0.f;
+	const bool inside = origin.x > 0.f && origin.x < sc.grid_size_f && origin.y > 0.f && origin.y < sc.grid_size_f && origin.z > 0.f &&
+						origin.z < sc.grid_height_f && (dir.x != 0.f || dir.y != 0.f || dir.z != 0.f);
+	if (!inside) {
+		const f3 t1 = (mk(0.f, 0.f, 0.f) - origin) / dir;
+		const f3 t2 = (mk(sc.grid_size_f, sc.grid_size_f, sc.grid_height_f) - origin) / dir;
+		const f3 tMin = mk(gmin(t1.x, t2.x), gmin(t1.y, t2.y), gmin(t1.z, t2.z));
+		const f3 tMax = mk(gmax(t1.x, t2.x), gmax(t1.y, t2.y), gmax(t1.z, t2.z));
+		tminn = gmax(gmax(tMin.x, 0.f), gmax(tMin.y, tMin.z));
+		if (!(gmin(tMax.x, gmin(tMax.y, tMax.z)) > tminn)) return ST_NEED;
+	}
 	r.tminn = tminn;
 	if (tminn > 0) { // move the ray onto the box and derive the entry-face normal (voxel.cuh:142-155)
 		origin = origin + dir * tminn;
@@ -304,7 +310,7 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 		if (DBG) tally.byte_tests++;
 		int sub = 0;
 		const f3 o2 = (r.o + r.d * new_distance) * 2.f - r.n * 0.2f * kEpsilon;
-		if (intersect_grid<2, DBG>(o2, r.d, r.n, sub_distance, nullptr, (index & kLodBits) >> 12, sub, tally)) {
+		if (intersect_grid<2, DBG>(o2, r.d, r.sx, r.sy, r.sz, r.dx, r.dy, r.dz, r.n, sub_distance, nullptr, (index & kLodBits) >> 12, sub, tally)) {
 			r.distance = new_distance * 8.f + sub_distance * 4.f + r.tminn;
 			if (DBG) { info.level = 1; info.sub_id = sub; }
 			r.hit = true;
@@ -316,7 +322,7 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 		const uint32_t slot = r.brick_base + (index & kIndexBits);
 		const uint32_t* brick = sc.brick_arena + (static_cast<size_t>(slot) << 4);
 		const f3 o8 = (r.o + r.d * new_distance) * 8.f - r.n * kEpsilon;
-		if (intersect_grid<8, DBG>(o8, r.d, r.n, sub_distance, brick, 0u, sub, tally)) {
+		if (intersect_grid<8, DBG>(o8, r.d, r.sx, r.sy, r.sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally)) {
 			r.distance = new_distance * 8.f + sub_distance + r.tminn;
 			if (DBG) { info.level = 2; info.sub_id = sub; }
 			r.hit = true;
