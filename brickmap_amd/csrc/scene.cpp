@@ -138,6 +138,10 @@ int Scene::init(int grid_size, int grid_height) {
 		set_error("grid_size and grid_height must be positive multiples of 128 voxels");
 		return BM_EINVAL;
 	}
+	if (world.dims.cells > 1024 || world.dims.cells_height > 1024) { // the traversal packs a brick cell into 3 x 10 bits
+		set_error("worlds larger than 8192 voxels per side are not supported");
+		return BM_EINVAL;
+	}
 	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipStreamCreateWithFlags(&load_stream_, hipStreamNonBlocking));
 	BM_HIP(hipStreamCreateWithFlags(&kernel_stream_, hipStreamNonBlocking));

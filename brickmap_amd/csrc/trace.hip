@@ -478,7 +478,6 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 	uint32_t xy = 0;          // x | y << 16
 	uint32_t p = 0;           // global pixel index y*W + x
 	uint32_t local_pixel = 0; // index into this shard's packed buffers
-	float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 	Tally tally;
 	HitInfo info;
 	uint32_t d0 = 0, d1 = 0, d2 = 0xFFFFFFFFu, d3 = 0, hseg = 2166136261u, hsh = 2166136261u, next = 0, nsh = 0, loads0 = 0;
@@ -531,7 +530,6 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 						p = static_cast<uint32_t>(y) * W + static_cast<uint32_t>(x);
 						local_pixel = static_cast<uint32_t>(ly) * W + static_cast<uint32_t>(x);
 						xy = static_cast<uint32_t>(x) | (static_cast<uint32_t>(y) << 16);
-						acc = accum[local_pixel];
 						s = 0;
 						pstate = P_GEN;
 						state = ST_NEED;
@@ -594,6 +592,7 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 					const bool primary_only = fc.flags & 1u; // BM_FLAG_PRIMARY_ONLY
 					// direction whose sky terms are needed: the ray itself on a miss, the sun sample on a hit
 					f3 view = r.d; // RayQueue::direction of the extend ray that just finished
+					f3 miss_color = mk(0.f, 0.f, 0.f);
 					float sunLight = 0.f;
 					bool cast = false;
 					if (is_hit && !primary_only) {
@@ -609,7 +608,7 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 						cast = sunLight > 0.f;
 						terminated = !(bounces < fc.max_bounces);
 						if (terminated) {
-							acc.w += 1.f; // kernel.cu:301
+							accum[local_pixel].w += 1.f; // kernel.cu:301
 						} else {
 							// kernel.cu:281-299: cosine-weighted bounce, drawn right after the cone sample as in shade();
 							// the direction is kept in `bdir` until the shadow ray (if any) has been traced.
@@ -641,19 +640,21 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 							f3 c;
 							if (bounces == 0) c = fc.sun_angular_cos == 1.0f ? mk(1.0f, 0.0f, 0.0f) : sunsky_from_view(fc, sv);
 							else c = sky_from_view(fc, sv);
-							acc.x += c.x; acc.y += c.y; acc.z += c.z;
+							miss_color = c;
 						}
 					}
-					if (!is_hit || primary_only) { // the path ends here
-						acc.w += 1.f;
+					if (!is_hit || primary_only) { // the path ends here: one read-modify-write of the pixel's accumulator
+						float4 a = accum[local_pixel];
+						a.x += miss_color.x; a.y += miss_color.y; a.z += miss_color.z; // (0,0,0) for a primary-only hit
+						a.w += 1.f;
+						accum[local_pixel] = a;
 						s++;
 						pstate = P_GEN;
 					}
 				}
 				if (pstate == P_GEN) {
 					if (s >= fc.spp) {
-						// pixel finished: publish it and wait for the next one
-						accum[local_pixel] = acc;
+						// pixel finished (its accumulator lives in memory and is already up to date): wait for the next one
 						if (DBG && dbg) {
 							uint32_t* d = dbg + static_cast<size_t>(local_pixel) * 8;
 							d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = hseg; d[5] = hsh; d[6] = next | (nsh << 16);
@@ -729,7 +730,11 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 						hsh = hmix(hsh, static_cast<uint32_t>(info.sub_id) | (static_cast<uint32_t>(info.level) << 12));
 					}
 				}
-				if (!occluded) { acc.x += scolor.x; acc.y += scolor.y; acc.z += scolor.z; }
+				if (!occluded) {
+					float4 a = accum[local_pixel];
+					a.x += scolor.x; a.y += scolor.y; a.z += scolor.z;
+					accum[local_pixel] = a;
+				}
 				if (terminated) {
 					s++;
 					pstate = P_GEN;
