@@ -36,6 +36,10 @@ def workload(name):
         "config1": (256, 256, 1, 0, 1, False),
         "config2": (1920, 1080, 1, 3, 8, False),
         "config3": (3840, 2160, 4, 7, 16, True),
+        # config 4 is config 3 at 16 spp over 8 GPUs (run with --gpus 8 --workload config4: 2 spp per rank-step)
+        "config4": (3840, 2160, 2, 7, 16, True),
+        # config 5: 8K, LoD on (reference thresholds), 32^3 superchunks; 32 spp over 8 GPUs = 4 spp per rank-step
+        "config5": (7680, 4320, 4, 7, 32, False),
     }
     return table[name]
 
