@@ -201,7 +201,8 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 	// divisions are only needed for rays that start on or outside the boundary.
 	float tminn = 0.f;
 	const bool inside = origin.x > 0.f && origin.x < sc.grid_size_f && origin.y > 0.f && origin.y < sc.grid_size_f && origin.z > 0.f &&
-						origin.z < sc.grid_height_f && (dir.x != 0.f || dir.y != 0.f || dir.z != 0.f);
+						origin.z < sc.grid_height_f && (dir.x != 0.f || dir.y != 0.f || dir.z != 0.f) &&
+						dir.x == dir.x && dir.y == dir.y && dir.z == dir.z; // NaN directions (bounce off a zero normal) take the full test
 	if (!inside) {
 		const f3 t1 = (mk(0.f, 0.f, 0.f) - origin) / dir;
 		const f3 t2 = (mk(sc.grid_size_f, sc.grid_size_f, sc.grid_height_f) - origin) / dir;

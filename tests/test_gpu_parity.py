@@ -386,3 +386,56 @@ def test_scheduler_statistics(bm, orc, torch_cuda, scene256):
     assert s["step_lanes"] + c["extend_rays"] + c["shadow_rays"] >= c["index_loads"]  # every visited cell is a move or a ray start
     assert s["candidate_lanes"] >= c["brick_tests"] and s["shade_lanes"] >= c["extend_rays"] and s["connect_lanes"] == c["shadow_rays"]
     assert 0 < s["step_lanes"] <= 64 * s["step_runs"] and s["waves"] > 0
+
+
+def test_randomised_views_match_oracle(bm, orc, torch_cuda, scene256, world256):
+    """Seeded sweep over camera position (inside, on the boundary, outside), angles, sun, lens and sample offsets."""
+    rng = np.random.default_rng(20250614)
+    world256.reset_device(True)
+    for trial in range(24):
+        pos = tuple(float(v) for v in rng.uniform(-80, 336, size=3))
+        if trial % 4 == 0:  # exactly on a face / corner of the world box
+            pos = (0.0, float(rng.uniform(0, 256)), 256.0)
+        h, v = float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-1.5, 1.5))
+        sun = (float(rng.uniform(0, 1)), float(rng.uniform(0.02, 0.45)))
+        lens = float(rng.choice([0.0, 0.0, 0.4]))
+        W, H = int(rng.integers(17, 90)), int(rng.integers(9, 60))
+        spp, mb, sb = int(rng.integers(1, 4)), int(rng.integers(0, 6)), int(rng.integers(0, 50))
+        cam = bm.Camera(position=pos, horizontal_angle=h, vertical_angle=v, lensRadius=lens, focalDistance=float(rng.uniform(0.5, 3))).update()
+        ocam = orc.make_camera(cam.position, cam.direction, focal_distance=cam.focalDistance, lens_radius=lens)
+        p = bm.FrameParams(W, H, spp=spp, sample_base=sb, max_bounces=mb, sun_position=sun)
+        acc, dbg = gpu_render(bm, torch_cuda, scene256, cam, p)
+        oacc, odbg, _, _ = world256.render(ocam, orc.make_frame(W, H, spp=spp, max_bounces=mb, sample_base=sb, sun=sun))
+        assert np.array_equal(dbg, odbg), f"trial {trial}: pos={pos} h={h} v={v}"
+        finite = np.isfinite(oacc)
+        assert np.array_equal(np.isfinite(acc), finite), f"trial {trial}"
+        assert_radiance(np.where(finite, acc, 0), np.where(finite, oacc, 0))
+
+
+def test_config3_like_streaming_lod_at_scale(bm, orc, torch_cuda):
+    """BASELINE config 3 geometry at a reduced frame: 16^3 superchunks (2048^3 voxels), 8 segments, reference LoD
+    thresholds, bricks streamed in on demand to a steady state; every 40th row compared with the oracle."""
+    G, W, H = 2048, 960, 540
+    scene = bm.Scene(G, G, device=0)
+    scene.set_queue_capacity(1 << 20)
+    scene.generate()
+    cam, ocam = cameras(bm, orc, G)
+    p = bm.FrameParams(W, H, spp=2, max_bounces=7)
+    torch = torch_cuda
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    for _ in range(64):
+        scene.render(cam, p, acc)
+        if scene.process_load_queue() == 0:
+            break
+    else:
+        pytest.fail("no streaming steady state")
+    info = scene.info()
+    assert 0 < info["resident_bricks"] < info["total_bricks"]  # only what the rays touched was ever uploaded
+    acc, dbg = gpu_render(bm, torch, scene, cam, p)
+    w = orc.World(G, G)
+    w.reset_device(True)
+    oacc, odbg, _, _ = w.render(ocam, orc.make_frame(W, H, spp=2, max_bounces=7, band_rows=1, shard_rank=11, shard_count=40), threads=os.cpu_count() or 1)
+    rows = bm.dist.shard_rows(H, 1, 11, 40)
+    assert np.array_equal(dbg[rows], odbg[rows])
+    assert_radiance(acc[rows], oacc[rows])
+    scene.close()
