@@ -403,7 +403,12 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 	const int slot = static_cast<int>(launches_ % kTimingRing);
 	BM_HIP(hipMemsetAsync(d_work_counter_, 0, sizeof(uint32_t), stream)); // chunk counter of the persistent kernel
 	BM_HIP(hipEventRecord(ev_start_[slot], stream));
-	launch_trace(view_, fc, accum, dbg, (fp->flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr, d_work_counter_, instrumented,
+#ifdef BM_PHASE_TIMING
+	DeviceCounters* const counters_arg = d_counters_; // profiling build: the plain kernel reports its phase timers too
+#else
+	DeviceCounters* const counters_arg = (fp->flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr;
+#endif
+	launch_trace(view_, fc, accum, dbg, counters_arg, d_work_counter_, instrumented,
 				 compute_units_ * blocks_per_cu_[instrumented ? 1 : 0], stream);
 	BM_HIP(hipGetLastError());
 	BM_HIP(hipEventRecord(ev_stop_[slot], stream));

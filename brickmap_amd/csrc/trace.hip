@@ -467,6 +467,12 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_STEPS_PER_ROUND
 #define BM_STEPS_PER_ROUND 8
 #endif
+// -DBM_PHASE_TIMING: profiling build in which the plain kernel also reports the scheduler statistics
+#ifdef BM_PHASE_TIMING
+#define BM_TIMED true
+#else
+#define BM_TIMED DBG
+#endif
 template <bool DBG>
 __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants fc, float4* __restrict__ accum,
 												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters,
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 	uint32_t runsA = 0, lanesA = 0, runsB = 0, lanesB = 0, runsC = 0, lanesC = 0, runsD = 0, lanesD = 0; // wave-uniform scheduler statistics
 
 	unsigned long long cycA = 0, cycB = 0, cycC = 0, cycD = 0;
-	const unsigned long long t_begin = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
+	const unsigned long long t_begin = BM_TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
 
 	for (;;) {
 		// ---- refill: hand pixels to idle lanes, 16 (one 4x4 chunk) at a time
@@ -562,9 +568,9 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 		else if (nA > 0) phase = 0;
 		else phase = (nC >= nB && nC >= nD) ? 2 : (nB >= nD ? 1 : 3);
 
-		const unsigned long long t_phase = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
+		const unsigned long long t_phase = BM_TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
 		if (phase == 2) {
-			if (DBG) { runsC++; lanesC += nC; }
+			if (BM_TIMED) { runsC++; lanesC += nC; }
 			// ================= phase C: shade the finished extend ray / generate the next primary ray, then set the new ray up
 			if (state == ST_NEED) {
 				bool need_setup = false;
@@ -717,7 +723,7 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 				}
 			}
 		} else if (phase == 3) {
-			if (DBG) { runsD++; lanesD += nD; }
+			if (BM_TIMED) { runsD++; lanesD += nD; }
 			// ================= phase D: connect (kernel.cu:328-346) -- runs after shade within the same reference frame --
 			// then the stored bounce ray is set up
 			if (state == ST_CONN) {
@@ -749,7 +755,7 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 				}
 			}
 		} else if (phase == 1) {
-			if (DBG) { runsB++; lanesB += nB; }
+			if (BM_TIMED) { runsB++; lanesB += nB; }
 			// ================= phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask DDA, streaming request)
 			if (state == ST_CAND) {
 				const int st = process_candidate<DBG>(sc, fc.campos, r, info, tally);
@@ -759,14 +765,14 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 			// ================= phase A: brick-grid DDA moves; lanes that reach a non-empty cell or leave the grid wait
 #pragma unroll 1
 			for (int k = 0; k < BM_STEPS_PER_ROUND; ++k) {
-				if (DBG) { runsA++; lanesA += __popcll(__ballot(state == ST_OUTER)); }
+				if (BM_TIMED) { runsA++; lanesA += __popcll(__ballot(state == ST_OUTER)); }
 				if (state == ST_OUTER) {
 					const int st = outer_step<DBG>(sc, r, tally);
 					state = (st == ST_NEED && shadow) ? ST_CONN : st;
 				}
 			}
 		}
-		if (DBG) {
+		if (BM_TIMED) {
 			const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_phase;
 			if (phase == 0) cycA += dt; else if (phase == 1) cycB += dt; else if (phase == 2) cycC += dt; else cycD += dt;
 		}
@@ -780,12 +786,12 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 			for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
 			if (lane == 0 && t) atomicAdd(&counters->v[k], t);
 		}
-		if (lane == 0) {
-			const unsigned long long st[8] = {runsA, lanesA, runsB, lanesB, runsC, lanesC, runsD, lanesD};
-			for (int k = 0; k < 8; ++k) atomicAdd(&counters->sched[k], st[k]);
-			const unsigned long long cy[8] = {cycA, cycB, cycC, cycD, __builtin_amdgcn_s_memtime() - t_begin, 0ull, 0ull, 1ull};
-			for (int k = 0; k < 8; ++k) atomicAdd(&counters->cycles[k], cy[k]);
-		}
+	}
+	if (BM_TIMED && counters && lane == 0) {
+		const unsigned long long st[8] = {runsA, lanesA, runsB, lanesB, runsC, lanesC, runsD, lanesD};
+		for (int k = 0; k < 8; ++k) atomicAdd(&counters->sched[k], st[k]);
+		const unsigned long long cy[8] = {cycA, cycB, cycC, cycD, __builtin_amdgcn_s_memtime() - t_begin, 0ull, 0ull, 1ull};
+		for (int k = 0; k < 8; ++k) atomicAdd(&counters->cycles[k], cy[k]);
 	}
 }
 
@@ -853,8 +859,13 @@ void launch_trace(const DeviceScene& sc, const FrameConstants& fc, float* accum,
 		hipLaunchKernelGGL(trace_paths<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc, reinterpret_cast<float4*>(accum), dbg,
 						   counters, work_counter);
 	else
+#ifdef BM_PHASE_TIMING
+		hipLaunchKernelGGL(trace_paths<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc, reinterpret_cast<float4*>(accum), nullptr,
+						   counters, work_counter);
+#else
 		hipLaunchKernelGGL(trace_paths<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc, reinterpret_cast<float4*>(accum), nullptr,
 						   nullptr, work_counter);
+#endif
 }
 
 void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const uint32_t* indices_queue, uint32_t* arena, uint32_t count,
