@@ -83,6 +83,7 @@ SIGNATURES = {
     "bm_scene_get_info": (_i, [_vp, C.POINTER(bm_scene_info)]),
     "bm_scene_host_supercell": (_i, [_vp, _i, _vp, _u32p, _vp, C.c_uint32]),
     "bm_scene_device_indices": (_i, [_vp, _i, _vp]),
+    "bm_scene_device_brick": (_i, [_vp, _i, C.c_uint32, _vp]),
     "bm_scene_column_heights": (_i, [_vp, _i, _i, _vp]),
     "bm_host_column_heights": (_i, [_i, _i, _i, _i, _vp]),
     "bm_host_generate_supercell": (_i, [_i, _i, _i, _i, _i, _vp, _u32p, _vp, C.c_uint32]),

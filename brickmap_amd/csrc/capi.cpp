@@ -83,6 +83,8 @@ int bm_scene_host_supercell(bm_scene* scene, int supercell, uint32_t* indices409
 
 int bm_scene_device_indices(bm_scene* scene, int supercell, uint32_t* indices4096) { BM_NEED(scene); return scene->impl.device_indices(supercell, indices4096); }
 
+int bm_scene_device_brick(bm_scene* scene, int supercell, uint32_t device_slot, uint32_t* out16) { BM_NEED(scene); return scene->impl.device_brick(supercell, device_slot, out16); }
+
 int bm_scene_column_heights(bm_scene* scene, int sx, int sy, float* heights) {
 	BM_NEED(scene);
 	const bm::WorldDims& d = scene->impl.world.dims;

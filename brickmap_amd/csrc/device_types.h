@@ -15,11 +15,16 @@ namespace bm {
 //                                         block (bx,by,bz) of the supercell holds any non-empty brick;
 //                                         brick_base = first arena slot of the supercell (exclusive
 //                                         prefix sum of non-empty brick counts; replaces Brick**)
-//   fine_mask   u64[supercells * 64]      per 4x4x4-brick block: bit (cx + 4*cy + 16*cz) = "index word
-//                                         of that brick is non-zero".  Static (residency flags never make
-//                                         a word zero), so the DDA can skip the index load of empty cells
-//                                         while still performing the reference's per-cell arithmetic.
-//   brick_arena 64 B * total_bricks      exact-fit pool; slot = brick_base + (word & 0xFFF)
+//   block_info  16 B per 4x4x4-brick block {u64 mask, u32 base, u32 0}: mask bit (cx + 4*cy + 16*cz) = "index
+//                                         word of that brick is non-zero".  Static (residency flags never
+//                                         make a word zero), so the DDA can skip the index load of empty
+//                                         cells while still performing the reference's per-cell arithmetic.
+//                                         base = arena slot of the block's first brick: bricks are stored
+//                                         block by block in mask-bit order, so a brick's slot is
+//                                         base + popcount(mask below its bit) -- known before (and fetched
+//                                         in parallel with) its index word.
+//   brick_arena 64 B * total_bricks      exact-fit pool, every brick has a fixed home slot; the 12-bit slot of
+//                                         a device index word is that slot relative to brick_base
 //   load_queue  int3[queue_cap] + count  brick-request ring (voxel.cuh:228-245)
 struct SuperInfo {
 	unsigned long long coarse;
@@ -28,10 +33,17 @@ struct SuperInfo {
 };
 static_assert(sizeof(SuperInfo) == 16, "one dwordx4 per supercell");
 
+struct BlockInfo {
+	unsigned long long mask;
+	uint32_t base;
+	uint32_t reserved;
+};
+static_assert(sizeof(BlockInfo) == 16, "one dwordx4 per block");
+
 struct DeviceScene {
 	uint32_t* index_grid;
 	const SuperInfo* super_info;
-	const unsigned long long* fine_mask;
+	const BlockInfo* block_info;
 	const uint32_t* brick_arena; // 16 words per brick
 	int* load_queue;             // 3 ints per entry
 	uint32_t* load_queue_count;

@@ -206,11 +206,11 @@ int Scene::set_queue_capacity(int cap) {
 void Scene::free_device() {
 	if (d_index_grid_) hipFree(d_index_grid_);
 	if (d_super_info_) hipFree(d_super_info_);
-	if (d_fine_mask_) hipFree(d_fine_mask_);
+	if (d_block_info_) hipFree(d_block_info_);
 	if (d_arena_) hipFree(d_arena_);
 	d_index_grid_ = d_arena_ = nullptr;
 	d_super_info_ = nullptr;
-	d_fine_mask_ = nullptr;
+	d_block_info_ = nullptr;
 	on_device_ = false;
 }
 
@@ -231,21 +231,22 @@ int Scene::allocate_device() {
 	const size_t index_bytes = static_cast<size_t>(d.supercells) * kCellsPerSupercell * sizeof(uint32_t);
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_index_grid_), index_bytes));
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_super_info_), static_cast<size_t>(d.supercells) * sizeof(SuperInfo)));
-	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_fine_mask_), static_cast<size_t>(d.supercells) * 64 * sizeof(unsigned long long)));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_block_info_), static_cast<size_t>(d.supercells) * 64 * sizeof(BlockInfo)));
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_arena_), std::max<size_t>(64, static_cast<size_t>(total_bricks_) * sizeof(Brick))));
 	{
 		std::vector<SuperInfo> info(d.supercells);
-		std::vector<unsigned long long> fine(static_cast<size_t>(d.supercells) * 64);
+		std::vector<BlockInfo> blocks(static_cast<size_t>(d.supercells) * 64);
 		for (int i = 0; i < d.supercells; ++i) {
-			info[i] = SuperInfo{world.supercells[i].coarse_mask, brick_base_[i], 0u};
-			for (int b = 0; b < 64; ++b) fine[static_cast<size_t>(i) * 64 + b] = world.supercells[i].fine_mask[b];
+			const HostSupercell& c = world.supercells[i];
+			info[i] = SuperInfo{c.coarse_mask, brick_base_[i], 0u};
+			for (int b = 0; b < 64; ++b) blocks[static_cast<size_t>(i) * 64 + b] = BlockInfo{c.fine_mask[b], brick_base_[i] + c.block_base[b], 0u};
 		}
 		BM_HIP(hipMemcpy(d_super_info_, info.data(), info.size() * sizeof(SuperInfo), hipMemcpyHostToDevice));
-		BM_HIP(hipMemcpy(d_fine_mask_, fine.data(), fine.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+		BM_HIP(hipMemcpy(d_block_info_, blocks.data(), blocks.size() * sizeof(BlockInfo), hipMemcpyHostToDevice));
 	}
 	view_.index_grid = d_index_grid_;
 	view_.super_info = d_super_info_;
-	view_.fine_mask = d_fine_mask_;
+	view_.block_info = d_block_info_;
 	view_.brick_arena = d_arena_;
 	view_.cells = d.cells;
 	view_.cells_height = d.cells_height;
@@ -301,13 +302,21 @@ int Scene::preload_all() {
 	BM_HIP(hipDeviceSynchronize());
 	const WorldDims& d = world.dims;
 	std::vector<uint32_t> words(static_cast<size_t>(d.supercells) * kCellsPerSupercell);
+	std::vector<Brick> ordered;
 	for (int i = 0; i < d.supercells; ++i) {
 		HostSupercell& c = world.supercells[i];
-		std::memcpy(&words[static_cast<size_t>(i) * kCellsPerSupercell], c.indices.data(), kCellsPerSupercell * sizeof(uint32_t));
+		uint32_t* dst = &words[static_cast<size_t>(i) * kCellsPerSupercell];
+		for (int j = 0; j < kCellsPerSupercell; ++j) { // host word with the brick's home slot in the arena
+			const uint32_t w = c.indices[j];
+			dst[j] = w ? ((w & ~BM_BRICK_INDEX_BITS) | c.device_slot[w & BM_BRICK_INDEX_BITS]) : 0u;
+		}
 		c.resident = static_cast<uint32_t>(c.bricks.size());
-		if (!c.bricks.empty())
-			BM_HIP(hipMemcpyAsync(d_arena_ + static_cast<size_t>(brick_base_[i]) * kBrickWords, c.bricks.data(), c.bricks.size() * sizeof(Brick),
-								  hipMemcpyHostToDevice, load_stream_));
+		if (!c.bricks.empty()) {
+			ordered.resize(c.bricks.size());
+			for (size_t h = 0; h < c.bricks.size(); ++h) ordered[c.device_slot[h]] = c.bricks[h];
+			BM_HIP(hipMemcpy(d_arena_ + static_cast<size_t>(brick_base_[i]) * kBrickWords, ordered.data(), ordered.size() * sizeof(Brick),
+							 hipMemcpyHostToDevice));
+		}
 	}
 	BM_HIP(hipMemcpyAsync(d_index_grid_, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice, load_stream_));
 	BM_HIP(hipMemsetAsync(d_load_count_, 0, sizeof(uint32_t), load_stream_));
@@ -337,7 +346,9 @@ int Scene::process_load_queue(uint32_t* serviced) {
 		const uint32_t local = static_cast<uint32_t>((px % kSupercell) + (py % kSupercell) * kSupercell + (pz % kSupercell) * kSupercell * kSupercell);
 		const uint32_t word = c.indices[local];
 		std::memcpy(h_bricks_ + static_cast<size_t>(i) * kBrickWords, c.bricks[word & BM_BRICK_INDEX_BITS].data, sizeof(Brick));
-		h_indices_[i] = c.resident | BM_BRICK_LOADED_BIT | (word & BM_BRICK_LOD_BITS);
+		// the reference hands out slots in request order (gpu_index_highest++, Scene.cpp:224); here every brick has a
+		// fixed home slot in the exact-fit arena (block order), so the new index word carries that slot
+		h_indices_[i] = c.device_slot[word & BM_BRICK_INDEX_BITS] | BM_BRICK_LOADED_BIT | (word & BM_BRICK_LOD_BITS);
 		c.resident++;
 	}
 	// no pool growth (Scene.cpp:231-251): each supercell owns an exact-fit arena region, so `resident` can never overrun it
@@ -383,6 +394,18 @@ int Scene::device_indices(int supercell, uint32_t* out4096) {
 	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipDeviceSynchronize());
 	BM_HIP(hipMemcpy(out4096, d_index_grid_ + static_cast<size_t>(supercell) * kCellsPerSupercell, kCellsPerSupercell * 4, hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int Scene::device_brick(int supercell, uint32_t device_slot, uint32_t* out16) {
+	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
+	if (supercell < 0 || supercell >= world.dims.supercells || !out16 || device_slot >= world.supercells[supercell].bricks.size()) {
+		set_error("bad supercell or slot");
+		return BM_EINVAL;
+	}
+	BM_HIP(hipSetDevice(device_));
+	BM_HIP(hipDeviceSynchronize());
+	BM_HIP(hipMemcpy(out16, d_arena_ + (static_cast<size_t>(brick_base_[supercell]) + device_slot) * kBrickWords, sizeof(Brick), hipMemcpyDeviceToHost));
 	return 0;
 }
 

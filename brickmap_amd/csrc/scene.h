@@ -40,6 +40,7 @@ public:
 	int dump(const char* path);
 	int info(bm_scene_info* out);
 	int device_indices(int supercell, uint32_t* out4096);
+	int device_brick(int supercell, uint32_t device_slot, uint32_t* out16);
 	int render(const bm_camera* cam, const bm_frame_params* fp, float* accum, uint32_t* dbg, hipStream_t stream);
 	int resolve(const float* accum, float* out, long long n, hipStream_t stream);
 	int synchronize();
@@ -72,7 +73,7 @@ private:
 	// device memory (DeviceScene view)
 	uint32_t* d_index_grid_ = nullptr;
 	SuperInfo* d_super_info_ = nullptr;
-	unsigned long long* d_fine_mask_ = nullptr;
+	BlockInfo* d_block_info_ = nullptr;
 	uint32_t* d_arena_ = nullptr;
 	int* d_load_queue_ = nullptr;
 	uint32_t* d_load_count_ = nullptr;

@@ -69,7 +69,7 @@ struct HitInfo {
 };
 
 // ---- 8^3 bitmask DDA (voxel.cuh:79-133) and 2^3 LoD DDA (voxel.cuh:26-77): one body, N = 8 or 2.
-// `words` points at the 64-byte brick (N == 8); `byte` is the LoD mask from the index word (N == 2).
+// `brick` holds the 64-byte brick (N == 8); `byte` is the LoD mask from the index word (N == 2).
 // The brick is fetched once, as four 16-byte loads in flight together, and walked from registers: a
 // z-slice of the brick is exactly one 64-bit word (bit x + 8y), re-selected only when the walk changes z.
 struct BrickRegs {
@@ -92,12 +92,7 @@ __device__ __forceinline__ unsigned long long brick_slice(const BrickRegs& b, in
 // sign(d) and 1/d here (voxel.cuh:90-101) from the same direction, i.e. the very same values.
 template <int N, bool DBG>
 __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy, int sz, float dx, float dy, float dz, f3& normal, float& distance,
-											   const uint32_t* __restrict__ words, uint32_t byte, int& sub_id, Tally& tally) {
-	BrickRegs brick;
-	if (N == 8) { // issue the whole 64-byte read before the set-up arithmetic below
-		const uint4* q = reinterpret_cast<const uint4*>(words);
-		brick.q0 = q[0]; brick.q1 = q[1]; brick.q2 = q[2]; brick.q3 = q[3];
-	}
+											   const BrickRegs& brick, uint32_t byte, int& sub_id, Tally& tally) {
 	int px = static_cast<int>(origin.x), py = static_cast<int>(origin.y), pz = static_cast<int>(origin.z);
 	const float cbx = dir.x > 0.f ? static_cast<float>(px + 1) : static_cast<float>(px);
 	const float cby = dir.y > 0.f ? static_cast<float>(py + 1) : static_cast<float>(py);
@@ -166,7 +161,7 @@ struct RayState {
 	f3 n;               // normal carried in/out of the traversal (voxel.cuh:135 `normal`)
 	int axis;           // axis of the last move, -1 before the first
 	unsigned long long coarse, fine;
-	uint32_t brick_base;
+	uint32_t block_base; // arena slot of the current block's first brick
 	int sci;
 	float distance;     // result
 	bool hit;
@@ -176,14 +171,17 @@ enum : int { ST_NEED = 0, ST_OUTER = 1, ST_CAND = 2, ST_FIN = 3 };
 
 __device__ __forceinline__ void load_super(const DeviceScene& sc, RayState& r) {
 	r.sci = (r.px >> 4) + (r.py >> 4) * sc.sg_xy + (r.pz >> 4) * sc.sg_xy2;
-	const uint4 rec = *reinterpret_cast<const uint4*>(sc.super_info + r.sci);
+	const uint2 rec = *reinterpret_cast<const uint2*>(sc.super_info + r.sci);
 	r.coarse = static_cast<unsigned long long>(rec.x) | (static_cast<unsigned long long>(rec.y) << 32);
-	r.brick_base = rec.z;
 }
 __device__ __forceinline__ void load_block(const DeviceScene& sc, RayState& r) {
 	const int bi = ((r.px >> 2) & 3) + (((r.py >> 2) & 3) << 2) + (((r.pz >> 2) & 3) << 4);
 	r.fine = 0ull;
-	if ((r.coarse >> bi) & 1ull) r.fine = sc.fine_mask[(static_cast<size_t>(r.sci) << 6) + bi];
+	if ((r.coarse >> bi) & 1ull) {
+		const uint4 rec = *reinterpret_cast<const uint4*>(sc.block_info + (static_cast<size_t>(r.sci) << 6) + bi);
+		r.fine = static_cast<unsigned long long>(rec.x) | (static_cast<unsigned long long>(rec.y) << 32);
+		r.block_base = rec.z;
+	}
 }
 __device__ __forceinline__ bool cell_occupied(const RayState& r) {
 	const int ci = (r.px & 3) + ((r.py & 3) << 2) + ((r.pz & 3) << 4);
@@ -290,7 +288,15 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	const int px = r.px, py = r.py, pz = r.pz;
 	// inside the grid 0 <= pos < cells, so >>4 and &15 equal the reference's signed /16 and %16
 	const uint32_t flat = (static_cast<uint32_t>(r.sci) << 12) + static_cast<uint32_t>((px & 15) + ((py & 15) << 4) + ((pz & 15) << 8));
+	// Home slot of this brick: block base + rank of its bit in the block mask.  It does not depend on the index
+	// word, so the 64-byte brick read is issued together with the index-word read instead of behind it (every
+	// non-empty cell owns its slot whether or not the brick is resident, so the read is always in bounds).
+	const int ci = (px & 3) + ((py & 3) << 2) + ((pz & 3) << 4);
+	const uint32_t slot = r.block_base + static_cast<uint32_t>(__popcll(r.fine & ((1ull << ci) - 1ull)));
+	const uint4* bq = reinterpret_cast<const uint4*>(sc.brick_arena + (static_cast<size_t>(slot) << 4));
 	const uint32_t index = sc.index_grid[flat];
+	BrickRegs brick;
+	brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
 	float new_distance = 0.f;
 	if (r.axis != -1) {
 		r.n = mk(0.f, 0.f, 0.f);
@@ -311,7 +317,7 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 		if (DBG) tally.byte_tests++;
 		int sub = 0;
 		const f3 o2 = (r.o + r.d * new_distance) * 2.f - r.n * 0.2f * kEpsilon;
-		if (intersect_grid<2, DBG>(o2, r.d, r.sx, r.sy, r.sz, r.dx, r.dy, r.dz, r.n, sub_distance, nullptr, (index & kLodBits) >> 12, sub, tally)) {
+		if (intersect_grid<2, DBG>(o2, r.d, r.sx, r.sy, r.sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, (index & kLodBits) >> 12, sub, tally)) {
 			r.distance = new_distance * 8.f + sub_distance * 4.f + r.tminn;
 			if (DBG) { info.level = 1; info.sub_id = sub; }
 			r.hit = true;
@@ -320,8 +326,6 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	} else if (index & kLoadedBit) {
 		if (DBG) tally.brick_tests++;
 		int sub = 0;
-		const uint32_t slot = r.brick_base + (index & kIndexBits);
-		const uint32_t* brick = sc.brick_arena + (static_cast<size_t>(slot) << 4);
 		const f3 o8 = (r.o + r.d * new_distance) * 8.f - r.n * kEpsilon;
 		if (intersect_grid<8, DBG>(o8, r.d, r.sx, r.sy, r.sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally)) {
 			r.distance = new_distance * 8.f + sub_distance + r.tminn;

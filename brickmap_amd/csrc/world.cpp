@@ -168,6 +168,22 @@ void World::build_supercell(int sx, int sy, int sz, const float* heights) {
 					static_cast<uint32_t>(cell.bricks.size() - 1) | 0x80000000u | (lod << 12); // Scene.cpp:104
 			}
 	}
+	cell.build_device_order();
+}
+
+void HostSupercell::build_device_order() {
+	device_slot.assign(bricks.size(), 0);
+	uint16_t next = 0;
+	for (int block = 0; block < 64; ++block) {
+		block_base[block] = next;
+		const int bx = (block & 3) * 4, by = ((block >> 2) & 3) * 4, bz = (block >> 4) * 4;
+		for (int cell = 0; cell < 64; ++cell) {
+			if (!((fine_mask[block] >> cell) & 1ull)) continue;
+			const int x = bx + (cell & 3), y = by + ((cell >> 2) & 3), z = bz + (cell >> 4);
+			const uint32_t word = indices[x + y * kSupercell + z * kSupercell * kSupercell];
+			device_slot[word & 0xFFFu] = next++;
+		}
+	}
 }
 
 void World::generate_supercell(int sx, int sy, int sz) {

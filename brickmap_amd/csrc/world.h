@@ -25,6 +25,11 @@ struct HostSupercell {               // Scene::Supercell, Scene.h:21-29 (host pa
 	// occupancy summary for the GPU traversal: which 4x4x4-brick blocks / which bricks are non-empty
 	uint64_t coarse_mask = 0;
 	uint64_t fine_mask[64] = {};
+	// device arena order: bricks of a block are contiguous, blocks in index order, bricks in mask-bit order, so that
+	// the arena slot of a brick follows from its block's base and a popcount of the block mask
+	uint16_t block_base[64] = {};        // device slot (within the supercell) of each block's first brick
+	std::vector<uint16_t> device_slot;  // host brick number -> device slot within the supercell
+	void build_device_order();
 };
 
 struct WorldDims {

@@ -185,6 +185,11 @@ class Scene:
         check(self._L.bm_scene_device_indices(self.gpuScene, sc, idx.ctypes.data))
         return idx
 
+    def device_brick(self, sc, device_slot):
+        out = np.zeros(16, np.uint32)
+        check(self._L.bm_scene_device_brick(self.gpuScene, sc, device_slot, out.ctypes.data))
+        return out
+
     def column_heights(self, sx, sy):
         out = np.zeros((128, 128), np.float32)
         check(self._L.bm_scene_column_heights(self.gpuScene, sx, sy, out.ctypes.data))

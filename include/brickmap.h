@@ -130,6 +130,8 @@ BM_API int bm_scene_get_info(bm_scene* scene, bm_scene_info* info);
 BM_API int bm_scene_host_supercell(bm_scene* scene, int supercell, uint32_t* indices4096, uint32_t* brick_count,
                                    uint32_t* bricks, uint32_t brick_capacity);
 BM_API int bm_scene_device_indices(bm_scene* scene, int supercell, uint32_t* indices4096);
+/* the 64-byte brick stored at `device_slot` (the 12-bit slot of a DEVICE index word) of a supercell's arena region */
+BM_API int bm_scene_device_brick(bm_scene* scene, int supercell, uint32_t device_slot, uint32_t* brick16);
 BM_API int bm_scene_column_heights(bm_scene* scene, int sx, int sy, float* heights128x128);
 
 /* host-only world-build doors (no device needed): the terrain generator behind Scene::generate */

@@ -91,9 +91,22 @@ def test_world_on_device_matches_oracle(bm, orc, torch_cuda, scene256, world256)
     assert info["total_bricks"] == world256.total_bricks() and info["resident_bricks"] == info["total_bricks"]
     assert info["index_bytes"] == world256.nsc * 16384 and info["brick_bytes"] == 64 * info["total_bricks"]
     for sc in range(world256.nsc):
-        idx, bricks = scene256.host_supercell(sc)
-        assert np.array_equal(idx, world256.sc_indices(sc)) and np.array_equal(bricks, world256.sc_bricks(sc))
-        assert np.array_equal(scene256.device_indices(sc), world256.sc_indices(sc))
+        idx, bricks = scene256.host_supercell(sc)  # host side: the reference's words and brick order
+        want_idx, want_bricks = world256.sc_indices(sc), world256.sc_bricks(sc)
+        assert np.array_equal(idx, want_idx) and np.array_equal(bricks, want_bricks)
+        # device side: same flags / LoD byte; the 12-bit slot is the brick's home slot in the block-ordered arena
+        dev = scene256.device_indices(sc)
+        assert np.array_equal(dev & ~np.uint32(0xFFF), want_idx & ~np.uint32(0xFFF))
+        nz = np.flatnonzero(dev)
+        assert sorted((dev[nz] & 0xFFF).tolist()) == list(range(len(want_bricks)))  # a permutation of the slots
+        for local in nz[:: max(1, len(nz) // 40)]:
+            assert np.array_equal(scene256.device_brick(sc, int(dev[local] & 0xFFF)), want_bricks[want_idx[local] & 0xFFF])
+        # block order: slots increase with (block, bit) order
+        lx, ly, lz = nz % 16, (nz // 16) % 16, nz // 256
+        block = (lx >> 2) + 4 * (ly >> 2) + 16 * (lz >> 2)
+        bit = (lx & 3) + 4 * (ly & 3) + 16 * (lz & 3)
+        order = np.lexsort((bit, block))
+        assert np.array_equal(dev[nz][order] & 0xFFF, np.arange(len(nz), dtype=np.uint32))
 
 
 def test_config1_primary_rays_golden(bm, orc, torch_cuda):
