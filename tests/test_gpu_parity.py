@@ -452,3 +452,28 @@ def test_config3_like_streaming_lod_at_scale(bm, orc, torch_cuda):
     assert np.array_equal(dbg[rows], odbg[rows])
     assert_radiance(acc[rows], oacc[rows])
     scene.close()
+
+
+def test_config5_like_lod_world_at_scale(bm, orc, torch_cuda):
+    """BASELINE config 5 geometry: 32^3 superchunks (4096^3 voxels, 512 MiB index grid, ~4.3 GiB of bricks), reference
+    LoD thresholds (all three levels occur), 8 segments, at a reduced frame; every 64th row compared with the oracle."""
+    G, W, H = 4096, 1024, 576
+    scene = bm.Scene(G, G, device=0).generate().preload_all()
+    info = scene.info()
+    assert info["index_bytes"] == 512 * 1024 * 1024 and info["supercells"] == 32768
+    cam, ocam = cameras(bm, orc, G)
+    p = bm.FrameParams(W, H, spp=1, max_bounces=7, flags=bm.BM_FLAG_COUNTERS)
+    scene.counters_reset()
+    acc, dbg = gpu_render(bm, torch_cuda, scene, cam, p)
+    cnt = scene.counters()
+    assert cnt["byte_tests"] > 0 and cnt["brick_tests"] > 0
+    levels = set(((dbg[..., 1] >> 12) & 0xF)[dbg[..., 1] != 0].tolist())
+    assert {1, 2} <= levels, levels
+    w = orc.World(G, G, threads=os.cpu_count() or 1)
+    assert w.total_bricks() == info["total_bricks"]
+    w.reset_device(True)
+    oacc, odbg, _, _ = w.render(ocam, orc.make_frame(W, H, spp=1, max_bounces=7, band_rows=1, shard_rank=5, shard_count=64), threads=os.cpu_count() or 1)
+    rows = bm.dist.shard_rows(H, 1, 5, 64)
+    assert np.array_equal(dbg[rows], odbg[rows])
+    assert_radiance(acc[rows], oacc[rows])
+    scene.close()
