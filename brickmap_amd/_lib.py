@@ -74,6 +74,7 @@ SIGNATURES = {
     "bm_scene_destroy": (None, [_vp]),
     "bm_scene_set_lod": (_i, [_vp, _i, _i]),
     "bm_scene_set_queue_capacity": (_i, [_vp, _i]),
+    "bm_scene_set_streaming_mode": (_i, [_vp, _i]),
     "bm_scene_generate": (_i, [_vp, _i]),
     "bm_scene_generate_supercell": (_i, [_vp, _i, _i, _i]),
     "bm_scene_preload_all": (_i, [_vp]),

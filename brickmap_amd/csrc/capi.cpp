@@ -58,6 +58,7 @@ void bm_scene_destroy(bm_scene* scene) { delete scene; }
 
 int bm_scene_set_lod(bm_scene* scene, int lod8, int lod2) { BM_NEED(scene); return scene->impl.set_lod(lod8, lod2); }
 int bm_scene_set_queue_capacity(bm_scene* scene, int capacity) { BM_NEED(scene); return scene->impl.set_queue_capacity(capacity); }
+int bm_scene_set_streaming_mode(bm_scene* scene, int overlapped) { BM_NEED(scene); return scene->impl.set_streaming_mode(overlapped); }
 int bm_scene_generate(bm_scene* scene, int threads) { BM_NEED(scene); return scene->impl.generate(threads); }
 int bm_scene_generate_supercell(bm_scene* scene, int sx, int sy, int sz) { BM_NEED(scene); return scene->impl.generate_supercell(sx, sy, sz); }
 int bm_scene_preload_all(bm_scene* scene) { BM_NEED(scene); return scene->impl.preload_all(); }

@@ -114,14 +114,18 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp,
 Scene::~Scene() {
 	hipSetDevice(device_);
 	free_device();
-	if (h_positions_) hipHostFree(h_positions_);
+	for (int r = 0; r < 2; ++r) {
+		if (h_positions_[r]) hipHostFree(h_positions_[r]);
+		if (h_count_[r]) hipHostFree(h_count_[r]);
+		if (d_load_queue_[r]) hipFree(d_load_queue_[r]);
+		if (d_load_count_[r]) hipFree(d_load_count_[r]);
+	}
+	if (ev_snapshot_) hipEventDestroy(ev_snapshot_);
+	if (ev_frame_done_) hipEventDestroy(ev_frame_done_);
 	if (h_bricks_) hipHostFree(h_bricks_);
 	if (h_indices_) hipHostFree(h_indices_);
-	if (h_count_) hipHostFree(h_count_);
-	if (d_load_queue_) hipFree(d_load_queue_);
 	if (d_bricks_queue_) hipFree(d_bricks_queue_);
 	if (d_indices_queue_) hipFree(d_indices_queue_);
-	if (d_load_count_) hipFree(d_load_count_);
 	if (d_counters_) hipFree(d_counters_);
 	if (d_work_counter_) hipFree(d_work_counter_);
 	for (int i = 0; i < kTimingRing; ++i) {
@@ -150,9 +154,13 @@ int Scene::init(int grid_size, int grid_height) {
 		BM_HIP(hipEventCreate(&ev_stop_[i]));
 	}
 	BM_HIP(hipEventCreateWithFlags(&ev_upload_, hipEventDisableTiming));
-	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_count_), sizeof(uint32_t), hipHostMallocDefault));
-	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_load_count_), sizeof(uint32_t)));
-	BM_HIP(hipMemset(d_load_count_, 0, sizeof(uint32_t)));
+	BM_HIP(hipEventCreateWithFlags(&ev_snapshot_, hipEventDisableTiming));
+	BM_HIP(hipEventCreateWithFlags(&ev_frame_done_, hipEventDisableTiming));
+	for (int r = 0; r < 2; ++r) {
+		BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_count_[r]), sizeof(uint32_t), hipHostMallocDefault));
+		BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_load_count_[r]), sizeof(uint32_t)));
+		BM_HIP(hipMemset(d_load_count_[r], 0, sizeof(uint32_t)));
+	}
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_counters_), sizeof(DeviceCounters)));
 	BM_HIP(hipMemset(d_counters_, 0, sizeof(DeviceCounters)));
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_work_counter_), sizeof(uint32_t)));
@@ -166,24 +174,52 @@ int Scene::init(int grid_size, int grid_height) {
 
 int Scene::alloc_queue() {
 	BM_HIP(hipSetDevice(device_));
-	if (h_positions_) { hipHostFree(h_positions_); h_positions_ = nullptr; }
 	if (h_bricks_) { hipHostFree(h_bricks_); h_bricks_ = nullptr; }
 	if (h_indices_) { hipHostFree(h_indices_); h_indices_ = nullptr; }
-	if (d_load_queue_) { hipFree(d_load_queue_); d_load_queue_ = nullptr; }
 	if (d_bricks_queue_) { hipFree(d_bricks_queue_); d_bricks_queue_ = nullptr; }
 	if (d_indices_queue_) { hipFree(d_indices_queue_); d_indices_queue_ = nullptr; }
 	const size_t n = static_cast<size_t>(queue_cap_);
-	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_positions_), n * 3 * sizeof(int), hipHostMallocDefault)); // Scene.cpp:30
+	for (int r = 0; r < 2; ++r) {
+		if (h_positions_[r]) { hipHostFree(h_positions_[r]); h_positions_[r] = nullptr; }
+		if (d_load_queue_[r]) { hipFree(d_load_queue_[r]); d_load_queue_[r] = nullptr; }
+		BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_positions_[r]), n * 3 * sizeof(int), hipHostMallocDefault)); // Scene.cpp:30
+		BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_load_queue_[r]), n * 3 * sizeof(int)));                          // Scene.cpp:186
+		BM_HIP(hipMemset(d_load_queue_[r], 0, n * 3 * sizeof(int)));
+		BM_HIP(hipMemset(d_load_count_[r], 0, sizeof(uint32_t)));
+	}
 	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_bricks_), n * sizeof(Brick), hipHostMallocDefault));      // Scene.cpp:31
 	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_indices_), n * sizeof(uint32_t), hipHostMallocDefault));  // Scene.cpp:32
-	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_load_queue_), n * 3 * sizeof(int)));                          // Scene.cpp:186
-	BM_HIP(hipMemset(d_load_queue_, 0, n * 3 * sizeof(int)));
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_bricks_queue_), n * sizeof(Brick)));                          // Scene.cpp:189
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_indices_queue_), n * sizeof(uint32_t)));                      // Scene.cpp:190
-	BM_HIP(hipMemset(d_load_count_, 0, sizeof(uint32_t)));
-	view_.load_queue = d_load_queue_;
-	view_.load_queue_count = d_load_count_;
+	ring_cur_ = 0;
+	snapshot_pending_ = false;
+	view_.load_queue = d_load_queue_[0];
+	view_.load_queue_count = d_load_count_[0];
 	view_.queue_cap = static_cast<uint32_t>(queue_cap_);
+	return 0;
+}
+
+int Scene::set_streaming_mode(int overlapped) {
+	BM_HIP(hipSetDevice(device_));
+	BM_HIP(hipDeviceSynchronize());
+	if (snapshot_pending_) { // drain: the copied-out ring is serviced now, so no request is lost by switching modes
+		snapshot_pending_ = false;
+		const uint32_t count = std::min<uint32_t>(static_cast<uint32_t>(queue_cap_), *h_count_[ring_snapshot_]);
+		if (count > 0) {
+			if (int e = service_ring(ring_snapshot_, count)) return e;
+		}
+		BM_HIP(hipDeviceSynchronize());
+	}
+	if (overlapped_ && !overlapped && ring_cur_ != 0) {
+		// the blocking mode always works on ring 0: carry over whatever the last frame queued in ring 1
+		BM_HIP(hipMemcpy(d_load_queue_[0], d_load_queue_[1], static_cast<size_t>(queue_cap_) * 3 * sizeof(int), hipMemcpyDeviceToDevice));
+		BM_HIP(hipMemcpy(d_load_count_[0], d_load_count_[1], sizeof(uint32_t), hipMemcpyDeviceToDevice));
+		BM_HIP(hipMemset(d_load_count_[1], 0, sizeof(uint32_t)));
+		ring_cur_ = 0;
+		view_.load_queue = d_load_queue_[0];
+		view_.load_queue_count = d_load_count_[0];
+	}
+	overlapped_ = overlapped != 0;
 	return 0;
 }
 
@@ -290,7 +326,11 @@ int Scene::reset_residency() {
 			dst[j] = (c.indices[j] & BM_BRICK_LOADED_BIT) ? (BM_BRICK_UNLOADED_BIT | (c.indices[j] & BM_BRICK_LOD_BITS)) : 0u;
 	}
 	BM_HIP(hipMemcpy(d_index_grid_, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-	BM_HIP(hipMemset(d_load_count_, 0, sizeof(uint32_t)));
+	for (int r = 0; r < 2; ++r) BM_HIP(hipMemset(d_load_count_[r], 0, sizeof(uint32_t)));
+	ring_cur_ = 0;
+	snapshot_pending_ = false;
+	view_.load_queue = d_load_queue_[0];
+	view_.load_queue_count = d_load_count_[0];
 	resident_bricks_ = 0;
 	upload_pending_ = false;
 	return 0;
@@ -319,29 +359,26 @@ int Scene::preload_all() {
 		}
 	}
 	BM_HIP(hipMemcpyAsync(d_index_grid_, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice, load_stream_));
-	BM_HIP(hipMemsetAsync(d_load_count_, 0, sizeof(uint32_t), load_stream_));
+	for (int r = 0; r < 2; ++r) BM_HIP(hipMemsetAsync(d_load_count_[r], 0, sizeof(uint32_t), load_stream_));
 	BM_HIP(hipStreamSynchronize(load_stream_));
+	ring_cur_ = 0;
+	snapshot_pending_ = false;
+	view_.load_queue = d_load_queue_[0];
+	view_.load_queue_count = d_load_count_[0];
 	resident_bricks_ = total_bricks_;
 	upload_pending_ = false;
 	return 0;
 }
 
 // ---------------------------------------------------------------- streaming
-int Scene::process_load_queue(uint32_t* serviced) {
-	if (serviced) *serviced = 0;
-	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
-	BM_HIP(hipSetDevice(device_));
-	// the frame that raised the requests must have finished (launch_kernels ends with cudaDeviceSynchronize, kernel.cu:431)
-	if (launches_ > 0) BM_HIP(hipStreamSynchronize(last_stream_)); // nullptr = the default stream
-	BM_HIP(hipMemcpyAsync(h_count_, d_load_count_, sizeof(uint32_t), hipMemcpyDeviceToHost, load_stream_)); // Scene.cpp:202
-	BM_HIP(hipStreamSynchronize(load_stream_));
-	uint32_t count = std::min<uint32_t>(static_cast<uint32_t>(queue_cap_), *h_count_);                       // Scene.cpp:203
-	if (count == 0) return 0;
-	BM_HIP(hipMemcpyAsync(h_positions_, d_load_queue_, static_cast<size_t>(count) * 3 * sizeof(int), hipMemcpyDeviceToHost, load_stream_)); // :209
-	BM_HIP(hipStreamSynchronize(load_stream_));
+// Stage the first `count` requests of a ring (positions already in its pinned mirror), copy them up and scatter
+// them into the arena / index grid on the load stream (Scene.cpp:215-229 + the upload kernel, kernel.cu:141-151,412-413).
+int Scene::service_ring(int ring, uint32_t count) {
 	const WorldDims& d = world.dims;
-	for (uint32_t i = 0; i < count; ++i) { // stage bricks + new index words (Scene.cpp:215-227)
-		const int px = h_positions_[3 * i], py = h_positions_[3 * i + 1], pz = h_positions_[3 * i + 2];
+	const int* pos = h_positions_[ring];
+	if (upload_pending_) BM_HIP(hipEventSynchronize(ev_upload_)); // the staging buffers of the previous upload are free again
+	for (uint32_t i = 0; i < count; ++i) {
+		const int px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
 		HostSupercell& c = world.supercells[d.supercell_id(px / kSupercell, py / kSupercell, pz / kSupercell)];
 		const uint32_t local = static_cast<uint32_t>((px % kSupercell) + (py % kSupercell) * kSupercell + (pz % kSupercell) * kSupercell * kSupercell);
 		const uint32_t word = c.indices[local];
@@ -354,13 +391,63 @@ int Scene::process_load_queue(uint32_t* serviced) {
 	// no pool growth (Scene.cpp:231-251): each supercell owns an exact-fit arena region, so `resident` can never overrun it
 	BM_HIP(hipMemcpyAsync(d_bricks_queue_, h_bricks_, static_cast<size_t>(count) * sizeof(Brick), hipMemcpyHostToDevice, load_stream_));    // :228
 	BM_HIP(hipMemcpyAsync(d_indices_queue_, h_indices_, static_cast<size_t>(count) * sizeof(uint32_t), hipMemcpyHostToDevice, load_stream_)); // :229
-	launch_upload(view_, d_bricks_queue_, d_indices_queue_, d_arena_, count, load_stream_); // kernel.cu:412
+	// The scatter kernel rewrites index words that a frame still in flight may be reading and requesting through
+	// (plain load + atomicOr): a word flipping to "loaded" between the two would be requested a second time.  In
+	// overlapped mode it therefore runs behind that frame (ev_frame_done_); the copies above already overlap it.
+	if (overlapped_ && launches_ > 0) BM_HIP(hipStreamWaitEvent(load_stream_, ev_frame_done_, 0));
+	DeviceScene ring_view = view_;
+	ring_view.load_queue = d_load_queue_[ring];
+	ring_view.load_queue_count = d_load_count_[ring];
+	launch_upload(ring_view, d_bricks_queue_, d_indices_queue_, d_arena_, count, load_stream_); // kernel.cu:412
 	BM_HIP(hipGetLastError());
-	BM_HIP(hipMemsetAsync(d_load_count_, 0, sizeof(uint32_t), load_stream_));               // kernel.cu:413
+	BM_HIP(hipMemsetAsync(d_load_count_[ring], 0, sizeof(uint32_t), load_stream_));             // kernel.cu:413
 	BM_HIP(hipEventRecord(ev_upload_, load_stream_));
 	upload_pending_ = true;
 	resident_bricks_ += count;
-	if (serviced) *serviced = count;
+	return 0;
+}
+
+int Scene::process_load_queue(uint32_t* serviced) {
+	if (serviced) *serviced = 0;
+	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
+	BM_HIP(hipSetDevice(device_));
+	if (!overlapped_) {
+		// ---- reference order (main.cpp:142-144): the frame that raised the requests has finished (kernel.cu:431), the host
+		// reads the ring, stages, uploads; the next frame sees the bricks
+		if (launches_ > 0) BM_HIP(hipStreamSynchronize(last_stream_)); // nullptr = the default stream
+		BM_HIP(hipMemcpyAsync(h_count_[0], d_load_count_[0], sizeof(uint32_t), hipMemcpyDeviceToHost, load_stream_)); // Scene.cpp:202
+		BM_HIP(hipStreamSynchronize(load_stream_));
+		const uint32_t count = std::min<uint32_t>(static_cast<uint32_t>(queue_cap_), *h_count_[0]);                   // Scene.cpp:203
+		if (count == 0) return 0;
+		BM_HIP(hipMemcpyAsync(h_positions_[0], d_load_queue_[0], static_cast<size_t>(count) * 3 * sizeof(int), hipMemcpyDeviceToHost, load_stream_)); // :209
+		BM_HIP(hipStreamSynchronize(load_stream_));
+		if (int e = service_ring(0, count)) return e;
+		if (serviced) *serviced = count;
+		return 0;
+	}
+	// ---- overlapped mode: never wait for the GPU.  (1) service the ring that was copied out by the previous call,
+	// (2) start copying out the ring the last frame wrote, behind that frame, on the load stream, (3) hand the other
+	// ring to the next frame.  Request -> resident takes two frames, as in the reference.
+	if (launches_ > 0) BM_HIP(hipEventRecord(ev_frame_done_, last_stream_)); // "the last frame has finished", for the load stream
+	if (snapshot_pending_) {
+		BM_HIP(hipEventSynchronize(ev_snapshot_));
+		snapshot_pending_ = false;
+		const uint32_t count = std::min<uint32_t>(static_cast<uint32_t>(queue_cap_), *h_count_[ring_snapshot_]);
+		if (count > 0) {
+			if (int e = service_ring(ring_snapshot_, count)) return e;
+			if (serviced) *serviced = count;
+		}
+	}
+	if (launches_ > 0) BM_HIP(hipStreamWaitEvent(load_stream_, ev_frame_done_, 0));
+	const int ring = ring_cur_;
+	BM_HIP(hipMemcpyAsync(h_count_[ring], d_load_count_[ring], sizeof(uint32_t), hipMemcpyDeviceToHost, load_stream_));
+	BM_HIP(hipMemcpyAsync(h_positions_[ring], d_load_queue_[ring], static_cast<size_t>(queue_cap_) * 3 * sizeof(int), hipMemcpyDeviceToHost, load_stream_));
+	BM_HIP(hipEventRecord(ev_snapshot_, load_stream_));
+	snapshot_pending_ = true;
+	ring_snapshot_ = ring;
+	ring_cur_ = ring ^ 1;
+	view_.load_queue = d_load_queue_[ring_cur_];
+	view_.load_queue_count = d_load_count_[ring_cur_];
 	return 0;
 }
 

@@ -32,6 +32,7 @@ public:
 	int init(int grid_size, int grid_height); // Scene::Scene: streams + pinned staging
 	int set_lod(int lod8, int lod2);
 	int set_queue_capacity(int cap);
+	int set_streaming_mode(int overlapped);
 	int generate(int threads);                // Scene::generate
 	int generate_supercell(int sx, int sy, int sz);
 	int preload_all();
@@ -59,6 +60,7 @@ private:
 	int allocate_device();
 	void free_device();
 	int alloc_queue();
+	int service_ring(int ring, uint32_t count);
 
 	int device_;
 	bool on_device_ = false;
@@ -75,18 +77,23 @@ private:
 	SuperInfo* d_super_info_ = nullptr;
 	BlockInfo* d_block_info_ = nullptr;
 	uint32_t* d_arena_ = nullptr;
-	int* d_load_queue_ = nullptr;
-	uint32_t* d_load_count_ = nullptr;
+	// two request rings: the blocking (reference-order) mode only uses ring 0; the overlapped mode alternates them so
+	// that a frame can raise requests while the previous frame's ring is being copied out and serviced
+	int* d_load_queue_[2] = {nullptr, nullptr};
+	uint32_t* d_load_count_[2] = {nullptr, nullptr};
 	uint32_t* d_bricks_queue_ = nullptr;
 	uint32_t* d_indices_queue_ = nullptr;
 	DeviceCounters* d_counters_ = nullptr;
 	uint32_t* d_work_counter_ = nullptr; // chunk counter of the persistent trace kernel, zeroed before each launch
 	int compute_units_ = 0, blocks_per_cu_[2] = {0, 0};
 	// pinned staging (Scene.cpp:30-32)
-	int* h_positions_ = nullptr;
+	int* h_positions_[2] = {nullptr, nullptr};
 	uint32_t* h_bricks_ = nullptr;
 	uint32_t* h_indices_ = nullptr;
-	uint32_t* h_count_ = nullptr;
+	uint32_t* h_count_[2] = {nullptr, nullptr};
+	bool overlapped_ = false, snapshot_pending_ = false;
+	int ring_cur_ = 0, ring_snapshot_ = 0;
+	hipEvent_t ev_snapshot_ = nullptr, ev_frame_done_ = nullptr;
 
 	std::vector<uint32_t> brick_base_; // host copy of the prefix sums
 	uint64_t total_bricks_ = 0, resident_bricks_ = 0;

@@ -166,6 +166,11 @@ class Scene:
         check(self._L.bm_scene_set_queue_capacity(self.gpuScene, capacity))
         return self
 
+    def set_streaming_mode(self, overlapped):
+        """False: reference order (service right after the frame). True: double-buffered rings, no host wait."""
+        check(self._L.bm_scene_set_streaming_mode(self.gpuScene, int(bool(overlapped))))
+        return self
+
     def info(self):
         i = bm_scene_info()
         check(self._L.bm_scene_get_info(self.gpuScene, C.byref(i)))

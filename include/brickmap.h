@@ -109,6 +109,11 @@ BM_API void bm_scene_destroy(bm_scene* scene);
 /* variables.h:24-27,35 made runtime; call before bm_scene_generate. */
 BM_API int bm_scene_set_lod(bm_scene* scene, int lod_distance_8x8x8, int lod_distance_2x2x2);
 BM_API int bm_scene_set_queue_capacity(bm_scene* scene, int capacity);
+/* 0 (default): bm_scene_process_load_queue waits for the frame and services its requests at once (reference order,
+ * main.cpp:142-144).  1: overlapped -- two request rings alternate; the call services the ring copied out by the
+ * previous call and starts the asynchronous copy-out of the last frame's ring on the load stream, so the host never
+ * waits for the GPU (request -> resident = 2 frames, as in the reference). */
+BM_API int bm_scene_set_streaming_mode(bm_scene* scene, int overlapped);
 /* Scene::generate (Scene.cpp:118-194): CPU world build on `threads` host threads, then the
  * device allocations in the reference's initial state (nothing resident: unloaded|lod). */
 BM_API int bm_scene_generate(bm_scene* scene, int threads);

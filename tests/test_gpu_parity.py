@@ -477,3 +477,43 @@ def test_config5_like_lod_world_at_scale(bm, orc, torch_cuda):
     assert np.array_equal(dbg[rows], odbg[rows])
     assert_radiance(acc[rows], oacc[rows])
     scene.close()
+
+
+def test_overlapped_streaming_reaches_the_resident_image(bm, orc, torch_cuda):
+    """Overlapped request servicing (two rings, no host wait): same steady state as the all-resident scene, every
+    brick uploaded exactly once, requests land two calls after they were raised."""
+    G, W, H = 256, 160, 120
+    scene = bm.Scene(G, G, device=0)
+    scene.set_queue_capacity(256)  # several frames of back-pressure on the ring
+    scene.generate()
+    scene.set_streaming_mode(True)
+    cam, _ = cameras(bm, orc, G)
+    p = bm.FrameParams(W, H, spp=1, max_bounces=3)
+    torch = torch_cuda
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    scene.render(cam, p, acc)
+    assert scene.process_load_queue() == 0          # call 1 only starts the copy-out of frame 1's ring
+    scene.render(cam, p, acc)
+    assert scene.process_load_queue() == 256        # call 2 services frame 1's (full) ring
+    total, idle = 256, 0
+    for _ in range(400):
+        scene.render(cam, p, acc)
+        n = scene.process_load_queue()
+        total += n
+        idle = idle + 1 if n == 0 else 0
+        if idle >= 3:
+            break
+    assert idle >= 3
+    info = scene.info()
+    assert total == info["resident_bricks"] <= info["total_bricks"]
+    loaded = sum(int(np.count_nonzero(scene.device_indices(sc) & bm.BRICK_LOADED_BIT)) for sc in range(8))
+    requested = sum(int(np.count_nonzero(scene.device_indices(sc) & bm.BRICK_REQUESTED_BIT)) for sc in range(8))
+    assert loaded == total and requested == 0       # exactly once each, nothing left half-requested
+    a_stream, d_stream = gpu_render(bm, torch, scene, cam, p)
+    scene.process_load_queue()
+    scene.process_load_queue()
+    scene.set_streaming_mode(False)
+    scene.preload_all()
+    a_res, d_res = gpu_render(bm, torch, scene, cam, p)
+    assert np.array_equal(d_stream, d_res) and np.array_equal(a_stream, a_res)
+    scene.close()
