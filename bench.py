@@ -9,7 +9,8 @@ with the scene already resident in HBM.  N = 1 runs BASELINE.json configs[1]:
 1920x1080, 1 spp, 4-bounce (MAX_BOUNCES = 3 -> 4 segments), 8x8x8 superchunks, all bricks resident.
 N > 1 keeps the per-GPU work fixed (weak scaling): the frame is split into interleaved 16-row
 bands, every rank traces N*spp samples for its H/N rows, then the packed bands are gathered to
-rank 0 over RCCL (brickmap_amd/dist.py) -- the gather is inside the timed region.
+rank 0 over RCCL (brickmap_amd/dist.py); the gather of frame i overlaps the tracing of frame i+1 and every gather,
+including the last one, completes inside the timed region.
 
 metric: Mrays/s = width * height * spp_total * segments / seconds  (nominal rays).
 The line also carries `roofline` (algorithmic bytes of the kernel / its HIP-event duration against
@@ -101,12 +102,16 @@ def main():
         return bm.FrameParams(W, H, spp=spp_step, sample_base=step * spp_step, max_bounces=max_bounces, flags=flags,
                               band_rows=band, shard_rank=rank, shard_count=world)
 
+    # N > 1: the gather of frame i runs on RCCL's stream while frame i+1 is being traced (one gather in flight)
+    gatherer = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev) if world > 1 else None
+
     def one_step(step):
         scene.render(cam, params(step), accum)
         if streaming:
             scene.process_load_queue()
-        if world > 1:
-            return bm.dist.gather_frame(accum, H, band)
+        if gatherer is not None:
+            gatherer.finish()      # frame step-1 is complete on rank 0
+            gatherer.start(accum)  # snapshot + asynchronous gather of this frame
         return accum
 
     if streaming:  # reach streaming steady state before anything is timed
@@ -118,6 +123,8 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
+    if gatherer is not None:
+        gatherer.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -125,6 +132,8 @@ def main():
     t_start = time.perf_counter()
     for i in range(args.steps):
         one_step(args.warmup + i)
+    if gatherer is not None:
+        gatherer.finish()  # the last frame's gather is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -59,3 +59,57 @@ def gather_frame(local, height, band_rows, group=None, dst=0):
         return out.to(out_device)
     dist.gather(send, gather_list=None, dst=dst, group=group)
     return None
+
+
+class FrameGatherer:
+    """Pipelined form of gather_frame for a render loop: `start(local)` snapshots this rank's packed rows into a send
+    buffer and launches the gather asynchronously (on RCCL's stream, behind the work already queued on the current
+    stream), so that it overlaps the next frame's rendering; `finish()` waits for it and, on `dst`, returns the
+    assembled [height, W, C] frame (None elsewhere; the returned tensor is reused by the next finish()).  At most one
+    gather is in flight."""
+
+    def __init__(self, height, width, channels=4, band_rows=DEFAULT_BAND_ROWS, dtype=None, device=None, group=None, dst=0):
+        import torch
+        import torch.distributed as dist
+        self.height, self.band_rows, self.group, self.dst = height, band_rows, group, dst
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.counts = [len(shard_rows(height, band_rows, r, self.world)) for r in range(self.world)]
+        self.out_device = torch.device(device) if device is not None else torch.device("cpu")
+        dtype = dtype or torch.float32
+        # gloo (CPU tests / single-GPU smoke runs) has no device gather: stage through host memory there
+        self.stage_on_cpu = self.world > 1 and dist.get_backend(group) == "gloo"
+        buf_device = torch.device("cpu") if self.stage_on_cpu else self.out_device
+        shape = (max(self.counts), width, channels)
+        self.send = torch.zeros(shape, dtype=dtype, device=buf_device)
+        self.recv = [torch.empty(shape, dtype=dtype, device=buf_device) for _ in range(self.world)] if self.rank == dst else None
+        self.rows = ([torch.as_tensor(shard_rows(height, band_rows, r, self.world), device=buf_device, dtype=torch.long)
+                      for r in range(self.world)] if self.rank == dst else None)
+        self.out = torch.empty((height, width, channels), dtype=dtype, device=buf_device) if self.rank == dst else None
+        self.work = None
+        self.local = None
+
+    def start(self, local):
+        import torch.distributed as dist
+        assert self.work is None and self.local is None, "finish() the previous gather first"
+        assert local.shape[0] == self.counts[self.rank]
+        if self.world == 1:
+            self.local = local
+            return
+        self.send[: local.shape[0]].copy_(local)  # snapshot: the caller may keep accumulating into `local`
+        self.work = dist.gather(self.send, gather_list=self.recv, dst=self.dst, group=self.group, async_op=True)
+
+    def finish(self):
+        if self.world == 1:
+            out, self.local = self.local, None
+            return out
+        if self.work is None:
+            return None
+        self.work.wait()
+        self.work = None
+        if self.rank != self.dst:
+            return None
+        for r in range(self.world):
+            if self.rows[r].numel():
+                self.out.index_copy_(0, self.rows[r], self.recv[r][: self.counts[r]])
+        return self.out.to(self.out_device)

@@ -35,6 +35,18 @@ def main():
         print("DIST_OK", world)
     else:
         assert out is None
+    # pipelined form: two frames through the same gatherer, the second started before the first is read back
+    g = bdist.FrameGatherer(H, W, band_rows=band, device="cpu")
+    g.start(local)
+    first = g.finish()
+    first = first.clone() if first is not None else None  # the returned frame is only valid until the next finish()
+    g.start(local * 2)
+    second = g.finish()
+    if rank == 0:
+        assert np.array_equal(first.numpy(), want) and np.array_equal(second.numpy(), want * 2)
+        print("PIPE_OK", world)
+    else:
+        assert first is None and second is None
     dist.barrier()
     dist.destroy_process_group()
 
