@@ -16,6 +16,27 @@ from . import _lib
 from ._lib import bm_camera, bm_counters, bm_frame_params, bm_scene_info, check
 
 
+# The reference's fly-through presets (performance_measure.h:4-25): camera position + (horizontal, vertical) angle.
+# It lists 9 positions but only 8 angle pairs (and indexes both with the same counter, performance_measure.cpp:74-76);
+# the 8 complete pairs are kept.  World: the reference's native 4096 x 4096 x 512 voxels.
+FLYTHROUGH_VIEWS = (
+    ((512.0, 512.0, 300.0), (-61863.5, -0.501796)),
+    ((840.254, 832.446, 1169.88), (-61864.4, -0.429796)),
+    ((2227.83, 774.886, 204.955), (-61863.9, 0.0622036)),
+    ((3326.19, 2055.72, 44.7995), (-61864.2, -0.981796)),
+    ((7134.6, 1262.44, 5531.79), (-61865.2, -0.501796)),
+    ((11298.6, 3113.03, 598.019), (-61866.3, -0.141796)),
+    ((10921.4, 4774.14, 267.808), (-61859.4, 0.0142036)),
+    ((9961.29, 4508.12, 189.59), (-61857.2, -0.261796)),
+)
+
+
+def flythrough_camera(i):
+    """Camera of the reference's i-th fly-through viewpoint."""
+    pos, (h, v) = FLYTHROUGH_VIEWS[i % len(FLYTHROUGH_VIEWS)]
+    return Camera(position=pos, horizontal_angle=h, vertical_angle=v).update()
+
+
 def _f32(v):
     return np.asarray(v, dtype=np.float32)
 

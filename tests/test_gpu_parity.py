@@ -517,3 +517,24 @@ def test_overlapped_streaming_reaches_the_resident_image(bm, orc, torch_cuda):
     a_res, d_res = gpu_render(bm, torch, scene, cam, p)
     assert np.array_equal(d_stream, d_res) and np.array_equal(a_stream, a_res)
     scene.close()
+
+
+def test_reference_flythrough_views_on_native_world(bm, orc, torch_cuda):
+    """The reference's native world (4096 x 4096 x 512) from two of its fly-through viewpoints (one inside, one far
+    outside the world box, performance_measure.h:4-25); every 54th row compared with the oracle."""
+    scene = bm.Scene(4096, 512, device=0).generate().preload_all()
+    assert scene.info()["total_bricks"] == 8663747  # SURVEY.md [probe]
+    w = orc.World(4096, 512, threads=os.cpu_count() or 1)
+    w.reset_device(True)
+    W, H = 960, 540
+    for view in (0, 4):
+        cam = bm.flythrough_camera(view)
+        ocam = orc.make_camera(cam.position, cam.direction)
+        assert np.array_equal(np.float32(cam.direction), orc.camera_direction(*bm.FLYTHROUGH_VIEWS[view][1]))
+        acc, dbg = gpu_render(bm, torch_cuda, scene, cam, bm.FrameParams(W, H, spp=1, max_bounces=3))
+        oacc, odbg, _, _ = w.render(ocam, orc.make_frame(W, H, spp=1, max_bounces=3, band_rows=1, shard_rank=3, shard_count=54), threads=os.cpu_count() or 1)
+        rows = bm.dist.shard_rows(H, 1, 3, 54)
+        assert np.array_equal(dbg[rows], odbg[rows]), f"view {view}"
+        assert_radiance(acc[rows], oacc[rows])
+        assert np.count_nonzero(dbg[..., 1]) > 0  # the world is in view
+    scene.close()
