@@ -128,6 +128,8 @@ Scene::~Scene() {
 	if (d_indices_queue_) hipFree(d_indices_queue_);
 	if (d_counters_) hipFree(d_counters_);
 	if (d_work_counter_) hipFree(d_work_counter_);
+	if (d_frame_constants_) hipFree(d_frame_constants_);
+	if (h_frame_constants_) hipHostFree(h_frame_constants_);
 	for (int i = 0; i < kTimingRing; ++i) {
 		if (ev_start_[i]) hipEventDestroy(ev_start_[i]);
 		if (ev_stop_[i]) hipEventDestroy(ev_stop_[i]);
@@ -163,7 +165,9 @@ int Scene::init(int grid_size, int grid_height) {
 	}
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_counters_), sizeof(DeviceCounters)));
 	BM_HIP(hipMemset(d_counters_, 0, sizeof(DeviceCounters)));
-	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_work_counter_), sizeof(uint32_t)));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_work_counter_), kWorkCounterBytes));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_frame_constants_), kTimingRing * sizeof(FrameConstants)));
+	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_frame_constants_), kTimingRing * sizeof(FrameConstants), hipHostMallocDefault));
 	hipDeviceProp_t prop;
 	BM_HIP(hipGetDeviceProperties(&prop, device_));
 	compute_units_ = prop.multiProcessorCount; // main.cpp:97 sm_cores
@@ -511,14 +515,16 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 	}
 	const bool instrumented = dbg != nullptr || (fp->flags & BM_FLAG_COUNTERS);
 	const int slot = static_cast<int>(launches_ % kTimingRing);
-	BM_HIP(hipMemsetAsync(d_work_counter_, 0, sizeof(uint32_t), stream)); // chunk counter of the persistent kernel
+	BM_HIP(hipMemsetAsync(d_work_counter_, 0, kWorkCounterBytes, stream)); // chunk counters of the persistent kernel
+	h_frame_constants_[slot] = fc; // (a slot is reused only after kTimingRing further launches)
+	BM_HIP(hipMemcpyAsync(d_frame_constants_ + slot, h_frame_constants_ + slot, sizeof(FrameConstants), hipMemcpyHostToDevice, stream));
 	BM_HIP(hipEventRecord(ev_start_[slot], stream));
 #ifdef BM_PHASE_TIMING
 	DeviceCounters* const counters_arg = d_counters_; // profiling build: the plain kernel reports its phase timers too
 #else
 	DeviceCounters* const counters_arg = (fp->flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr;
 #endif
-	launch_trace(view_, fc, accum, dbg, counters_arg, d_work_counter_, instrumented,
+	launch_trace(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, d_work_counter_, instrumented,
 				 compute_units_ * blocks_per_cu_[instrumented ? 1 : 0], stream);
 	BM_HIP(hipGetLastError());
 	BM_HIP(hipEventRecord(ev_stop_[slot], stream));

@@ -84,6 +84,8 @@ private:
 	uint32_t* d_bricks_queue_ = nullptr;
 	uint32_t* d_indices_queue_ = nullptr;
 	DeviceCounters* d_counters_ = nullptr;
+	FrameConstants* d_frame_constants_ = nullptr; // kTimingRing device copies, one per in-flight launch
+	FrameConstants* h_frame_constants_ = nullptr; // pinned source of the copies
 	uint32_t* d_work_counter_ = nullptr; // chunk counter of the persistent trace kernel, zeroed before each launch
 	int compute_units_ = 0, blocks_per_cu_[2] = {0, 0};
 	// pinned staging (Scene.cpp:30-32)

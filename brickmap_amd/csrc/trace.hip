@@ -468,6 +468,9 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_WAVES_PER_SIMD
 #define BM_WAVES_PER_SIMD 4
 #endif
+#ifndef BM_WORK_COUNTERS
+#define BM_WORK_COUNTERS 8
+#endif
 #ifndef BM_STEPS_PER_ROUND
 #define BM_STEPS_PER_ROUND 8
 #endif
@@ -478,9 +481,12 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #define BM_TIMED DBG
 #endif
 template <bool DBG>
-__global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants fc, float4* __restrict__ accum,
+__global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, float4* __restrict__ accum,
 												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters,
 												  uint32_t* __restrict__ work_counter) {
+	// the per-frame constants live in device memory (not in the kernel-argument registers): they are read with scalar
+	// loads where they are needed, which keeps the scalar register file free for the scheduler loop
+	const FrameConstants& fc = *fcp;
 	const int lane = threadIdx.x & 63;
 	const uint32_t W = static_cast<uint32_t>(fc.width), H = static_cast<uint32_t>(fc.height);
 	const uint32_t total_chunks = static_cast<uint32_t>(fc.tiles_x) * static_cast<uint32_t>(fc.tiles_y) * 16u;
@@ -508,6 +514,9 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 	f3 bdir = mk(0.f, 0.f, 0.f);   // next bounce direction, drawn in shade, used once the shadow ray is done
 
 	bool work_left = true;
+	constexpr uint32_t kCounters = BM_WORK_COUNTERS, kCounterStride = 32; // one 128-byte line per counter
+	int my_counter = static_cast<int>((blockIdx.x * 4u + (threadIdx.x >> 6)) % kCounters);
+	int counters_done = 0;
 	// hang guard only (NaN directions): no wave needs more scheduler rounds than this
 	long long rounds_left = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fc.spp) + 1) * (fc.max_bounces + 2) *
 							(2ll * sc.cells + sc.cells_height + 64);
@@ -521,15 +530,29 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 		const unsigned long long idle = __ballot(state == ST_IDLE);
 		const int nI = __popcll(idle);
 		if (work_left && nI >= 16) {
+			// One global word serves only ~90 returning atomics per microsecond chip-wide, and a refill stalls the whole
+			// wave until its atomic returns; with thousands of waves on one counter that queue is tens of microseconds
+			// long.  The chunk sequence is therefore dealt to kCounters interleaved counters (8x8-pixel groups of four
+			// chunks, group g on counter g % kCounters, each counter on its own cache line): every counter still sweeps
+			// the image top-down, so concurrently running waves keep working on neighbouring rows of the image.
 			const int want = nI >> 4;
 			uint32_t base = 0;
-			if (lane == 0) base = atomicAdd(work_counter, static_cast<uint32_t>(want));
+			if (lane == 0) base = atomicAdd(work_counter + my_counter * kCounterStride, static_cast<uint32_t>(want));
 			base = __builtin_amdgcn_readfirstlane(base);
-			if (base + want >= total_chunks) work_left = false;
+			const uint32_t total_groups = (total_chunks + 3u) >> 2;
+			const uint32_t my_groups = total_groups > static_cast<uint32_t>(my_counter)
+										   ? (total_groups - static_cast<uint32_t>(my_counter) + kCounters - 1u) / kCounters : 0u;
+			const uint32_t my_tickets = my_groups * 4u;
+			const uint32_t counter_now = static_cast<uint32_t>(my_counter);
+			if (base + want >= my_tickets) { // this counter is used up: move to the next one (helping out), or finish
+				my_counter = (my_counter + 1) % static_cast<int>(kCounters);
+				if (++counters_done >= static_cast<int>(kCounters)) work_left = false;
+			}
 			const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
 			if (state == ST_IDLE && rank < want * 16) {
-				const uint32_t chunk = base + static_cast<uint32_t>(rank >> 4);
-				if (chunk < total_chunks) {
+				const uint32_t ticket = base + static_cast<uint32_t>(rank >> 4);
+				const uint32_t chunk = ((ticket >> 2) * kCounters + counter_now) * 4u + (ticket & 3u);
+				if (ticket < my_tickets && chunk < total_chunks) {
 					const uint32_t tile = chunk >> 4, k = chunk & 15u;
 					const int tile_x = static_cast<int>(tile % static_cast<uint32_t>(fc.tiles_x));
 					const int tile_y = static_cast<int>(tile / static_cast<uint32_t>(fc.tiles_x));
@@ -853,21 +876,21 @@ int trace_blocks_per_cu(bool instrumented) {
 
 // Persistent launch: exactly as many 256-thread workgroups as the device keeps resident (compute_units x
 // blocks per CU); the waves pull 4x4-pixel chunks from *work_counter, which must be zero at launch.
-void launch_trace(const DeviceScene& sc, const FrameConstants& fc, float* accum, uint32_t* dbg, DeviceCounters* counters, uint32_t* work_counter,
-				  bool instrumented, int resident_blocks, hipStream_t stream) {
+void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameConstants* fc_dev, float* accum, uint32_t* dbg, DeviceCounters* counters,
+				  uint32_t* work_counter, bool instrumented, int resident_blocks, hipStream_t stream) {
 	const long long chunks = static_cast<long long>(fc.tiles_x) * fc.tiles_y * 16;
 	if (chunks <= 0) return;
 	long long blocks = (chunks + 15) / 16; // never more workgroups than 64-pixel groups
 	if (blocks > resident_blocks) blocks = resident_blocks;
 	if (instrumented)
-		hipLaunchKernelGGL(trace_paths<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc, reinterpret_cast<float4*>(accum), dbg,
+		hipLaunchKernelGGL(trace_paths<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc_dev, reinterpret_cast<float4*>(accum), dbg,
 						   counters, work_counter);
 	else
 #ifdef BM_PHASE_TIMING
-		hipLaunchKernelGGL(trace_paths<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc, reinterpret_cast<float4*>(accum), nullptr,
+		hipLaunchKernelGGL(trace_paths<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc_dev, reinterpret_cast<float4*>(accum), nullptr,
 						   counters, work_counter);
 #else
-		hipLaunchKernelGGL(trace_paths<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc, reinterpret_cast<float4*>(accum), nullptr,
+		hipLaunchKernelGGL(trace_paths<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc_dev, reinterpret_cast<float4*>(accum), nullptr,
 						   nullptr, work_counter);
 #endif
 }
