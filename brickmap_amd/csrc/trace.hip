@@ -471,6 +471,12 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_WORK_COUNTERS
 #define BM_WORK_COUNTERS 8
 #endif
+#ifndef BM_QUORUM_DIV
+#define BM_QUORUM_DIV 4
+#endif
+#ifndef BM_QUORUM_CONN_DIV
+#define BM_QUORUM_CONN_DIV 8
+#endif
 #ifndef BM_STEPS_PER_ROUND
 #define BM_STEPS_PER_ROUND 8
 #endif
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const Devi
 		if (--rounds_left < 0) break;
 		// Policy: an expensive phase runs once a quarter of the live lanes wait for it, the cheap connect phase
 		// once an eighth does; otherwise the DDA keeps moving.  With no lane left in the DDA the largest group runs.
-		const int quorum = (live + 3) / 4, quorum_conn = (live + 7) / 8;
+		const int quorum = (live + BM_QUORUM_DIV - 1) / BM_QUORUM_DIV, quorum_conn = (live + BM_QUORUM_CONN_DIV - 1) / BM_QUORUM_CONN_DIV;
 		int phase; // 0 = A (DDA moves), 1 = B (candidates), 2 = C (shade / generate), 3 = D (connect)
 		if (nC >= quorum) phase = 2;
 		else if (nB >= quorum) phase = 1;
