@@ -487,7 +487,8 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #define BM_TIMED DBG
 #endif
 template <bool DBG>
-__global__ __launch_bounds__(256, BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, float4* __restrict__ accum,
+// (the instrumented variant carries hit records and counters: it gets the registers instead of the occupancy)
+__global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, float4* __restrict__ accum,
 												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters,
 												  uint32_t* __restrict__ work_counter) {
 	// the per-frame constants live in device memory (not in the kernel-argument registers): they are read with scalar
