@@ -236,15 +236,17 @@ def cpu_baseline(W, H, spp, max_bounces, G, cam):
 
 def pmc_traffic(workload):
     """HBM bytes per launch from the committed rocprofv3 PMC summary of this workload (separate --pmc passes,
-    tools/pmc.sh), or None.  FETCH_SIZE / WRITE_SIZE are in KiB; the gfx950 x2 correction of the guide applies to
-    wide coalesced streams only and is NOT applied here (this kernel issues 4-16 B gathers): see DESIGN.md."""
+    tools/pmc.sh), or None.  Units and correction as MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and
+    WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, i.e. reports half of a 16 B/lane
+    stream, so it is doubled (this kernel's traffic is dominated by the 16-byte brick / mask-record reads);
+    WRITE_SIZE is taken as reported (uncalibrated per the guide)."""
     path = os.path.join(ROOT, "profiles", "pmc_summary.json")
     try:
         with open(path) as f:
             d = json.load(f)
         if d.get("workload") != workload:
             return None
-        return int((d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024)
+        return int((2.0 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024)
     except (OSError, KeyError, ValueError):
         return None
 
