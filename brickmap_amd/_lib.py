@@ -102,6 +102,13 @@ SIGNATURES = {
     "bm_counters_read": (_i, [_vp, C.POINTER(bm_counters)]),
     "bm_counters_reset": (_i, [_vp]),
     "bm_sched_stats_read": (_i, [_vp, C.POINTER(bm_sched_stats)]),
+    "bm_wavefront_create": (_i, [_vp, C.c_uint32, C.POINTER(_vp)]),
+    "bm_wavefront_destroy": (None, [_vp]),
+    "bm_wavefront_reset": (_i, [_vp]),
+    "bm_wavefront_frame": (_i, [_vp, C.POINTER(bm_camera), C.POINTER(bm_frame_params), _vp, _vp]),
+    "bm_wavefront_stats": (_i, [_vp, _u32p]),
+    "bm_wavefront_read_queue": (_i, [_vp, _i, C.c_uint32, C.c_uint32, _vp]),
+    "bm_wavefront_times": (_i, [_vp, C.POINTER(C.c_float)]),
     "bm_debug_sincos": (_i, [_i, _i, _vp, _vp, _vp]),
     "bm_debug_sky": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp]),
 }

@@ -4,10 +4,16 @@
 
 #include "kernels.h"
 #include "scene.h"
+#include "wavefront.h"
 
 struct bm_scene {
 	bm::Scene impl;
 	explicit bm_scene(int device) : impl(device) {}
+};
+
+struct bm_wavefront {
+	bm::Wavefront impl;
+	bm_wavefront(bm::Scene* scene, uint32_t queue_size) : impl(scene, queue_size) {}
 };
 
 using bm::set_error;
@@ -176,6 +182,40 @@ int bm_render_times(bm_scene* scene, float* ms, int capacity, int* count) { BM_N
 int bm_counters_read(bm_scene* scene, bm_counters* out) { BM_NEED(scene); return scene->impl.counters_read(out); }
 int bm_counters_reset(bm_scene* scene) { BM_NEED(scene); return scene->impl.counters_reset(); }
 int bm_sched_stats_read(bm_scene* scene, bm_sched_stats* out) { BM_NEED(scene); return scene->impl.sched_stats_read(out); }
+
+int bm_wavefront_create(bm_scene* scene, uint32_t queue_size, bm_wavefront** out) {
+	BM_NEED(scene);
+	if (!out) { set_error("null argument"); return BM_EINVAL; }
+	*out = nullptr;
+	bm_wavefront* w = new (std::nothrow) bm_wavefront(&scene->impl, queue_size);
+	if (!w) { set_error("out of host memory"); return BM_EINVAL; }
+	if (int e = w->impl.init()) {
+		delete w;
+		return e;
+	}
+	*out = w;
+	return 0;
+}
+void bm_wavefront_destroy(bm_wavefront* wf) { delete wf; }
+#define BM_NEED_WF(wf)                                   \
+	do {                                                 \
+		if (!(wf)) {                                     \
+			set_error("null wavefront handle");          \
+			return BM_EINVAL;                            \
+		}                                                \
+	} while (0)
+int bm_wavefront_reset(bm_wavefront* wf) { BM_NEED_WF(wf); return wf->impl.reset(); }
+int bm_wavefront_frame(bm_wavefront* wf, const bm_camera* camera, const bm_frame_params* params, float* accum_dev, void* hip_stream) {
+	BM_NEED_WF(wf);
+	if (!camera || !params) { set_error("null argument"); return BM_EINVAL; }
+	return wf->impl.frame(camera, params, accum_dev, static_cast<hipStream_t>(hip_stream));
+}
+int bm_wavefront_stats(bm_wavefront* wf, uint32_t* out6) { BM_NEED_WF(wf); return wf->impl.stats(out6); }
+int bm_wavefront_read_queue(bm_wavefront* wf, int which, uint32_t first, uint32_t count, void* host_out) {
+	BM_NEED_WF(wf);
+	return wf->impl.read_queue(which, first, count, host_out);
+}
+int bm_wavefront_times(bm_wavefront* wf, float* ms5) { BM_NEED_WF(wf); return wf->impl.times(ms5); }
 
 int bm_debug_sincos(int device, int n, const float* x_host, float* sin_host, float* cos_host) {
 	if (n <= 0 || !x_host || !sin_host || !cos_host) { set_error("bad argument"); return BM_EINVAL; }

@@ -89,4 +89,32 @@ struct DeviceCounters { // v: same order as bm_counters; sched: same order as bm
 	unsigned long long cycles[8]; // s_memtime ticks per scheduler phase, summed over waves: A, B, C, D, total, 0, 0, waves
 };
 
+// ---- wavefront mode (wavefront.hip): the reference's queue records and device globals
+struct WfRay { // RayQueue, variables.h:43-52 -- 64 bytes, same field order (four 16-byte loads per record)
+	float origin[3], direction[3], throughput[3], normal[3];
+	float distance;
+	int identifier;
+	int bounces;
+	uint32_t pixel_index;
+};
+static_assert(sizeof(WfRay) == 64, "RayQueue is 64 bytes");
+
+struct WfShadow { // ShadowQueue, variables.h:54-59 -- 40 bytes
+	float origin[3], direction[3], color[3];
+	uint32_t pixel_index;
+};
+static_assert(sizeof(WfShadow) == 40, "ShadowQueue is 40 bytes");
+
+struct WfState { // the __device__ globals of kernel.cu:106-119, plus the ticket counters of the persistent kernels
+	uint32_t primary_ray_cnt; // survivors written to the next queue by shade = rays already in the work queue
+	uint32_t shadow_ray_cnt;
+	uint32_t start_position;
+	uint32_t generated;       // primary rays generated by the last primary_rays launch
+	uint32_t last_survivors, last_shadow;
+	uint32_t reserved[26];
+	uint32_t extend_ticket[32];  // [0] is used; each counter on its own 128-byte line
+	uint32_t connect_ticket[32];
+};
+static_assert(sizeof(WfState) == 384, "three 128-byte lines");
+
 } // namespace bm

@@ -1,4 +1,4 @@
-// kernels.h -- host-callable launchers implemented in trace.hip
+// kernels.h -- host-callable launchers implemented in trace.hip and wavefront.hip
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -14,4 +14,12 @@ void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const ui
 void launch_resolve(const float* accum, float* out, long long n, hipStream_t stream);
 void launch_debug_sincos(int n, const float* x, float* s, float* c, hipStream_t stream);
 void launch_debug_sky(const FrameConstants& fc, int n, const float* v, float* sun, float* sky, float* sunsky, hipStream_t stream);
+
+// wavefront mode (wavefront.hip)
+int wavefront_blocks_per_cu(bool connect, bool instrumented);
+void launch_wf_primary(WfState* st, WfRay* work, const FrameConstants* fc_dev, uint32_t queue_size, uint32_t pixels, hipStream_t stream);
+void launch_wf_trace(bool connect, const DeviceScene& sc, const FrameConstants* fc_dev, WfState* st, WfRay* work, const WfShadow* shadow, float* accum,
+					 DeviceCounters* counters, uint32_t queue_size, int resident_blocks, hipStream_t stream);
+void launch_wf_shade(const WfRay* work, WfRay* next, WfShadow* shadow, float* accum, void* block_counts, WfState* st, const FrameConstants* fc_dev,
+					 uint32_t queue_size, hipStream_t stream);
 } // namespace bm

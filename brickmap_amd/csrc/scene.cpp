@@ -398,7 +398,7 @@ int Scene::service_ring(int ring, uint32_t count) {
 	// The scatter kernel rewrites index words that a frame still in flight may be reading and requesting through
 	// (plain load + atomicOr): a word flipping to "loaded" between the two would be requested a second time.  In
 	// overlapped mode it therefore runs behind that frame (ev_frame_done_); the copies above already overlap it.
-	if (overlapped_ && launches_ > 0) BM_HIP(hipStreamWaitEvent(load_stream_, ev_frame_done_, 0));
+	if (overlapped_ && any_frame()) BM_HIP(hipStreamWaitEvent(load_stream_, ev_frame_done_, 0));
 	DeviceScene ring_view = view_;
 	ring_view.load_queue = d_load_queue_[ring];
 	ring_view.load_queue_count = d_load_count_[ring];
@@ -418,7 +418,7 @@ int Scene::process_load_queue(uint32_t* serviced) {
 	if (!overlapped_) {
 		// ---- reference order (main.cpp:142-144): the frame that raised the requests has finished (kernel.cu:431), the host
 		// reads the ring, stages, uploads; the next frame sees the bricks
-		if (launches_ > 0) BM_HIP(hipStreamSynchronize(last_stream_)); // nullptr = the default stream
+		if (any_frame()) BM_HIP(hipStreamSynchronize(last_stream_)); // nullptr = the default stream
 		BM_HIP(hipMemcpyAsync(h_count_[0], d_load_count_[0], sizeof(uint32_t), hipMemcpyDeviceToHost, load_stream_)); // Scene.cpp:202
 		BM_HIP(hipStreamSynchronize(load_stream_));
 		const uint32_t count = std::min<uint32_t>(static_cast<uint32_t>(queue_cap_), *h_count_[0]);                   // Scene.cpp:203
@@ -432,7 +432,7 @@ int Scene::process_load_queue(uint32_t* serviced) {
 	// ---- overlapped mode: never wait for the GPU.  (1) service the ring that was copied out by the previous call,
 	// (2) start copying out the ring the last frame wrote, behind that frame, on the load stream, (3) hand the other
 	// ring to the next frame.  Request -> resident takes two frames, as in the reference.
-	if (launches_ > 0) BM_HIP(hipEventRecord(ev_frame_done_, last_stream_)); // "the last frame has finished", for the load stream
+	if (any_frame()) BM_HIP(hipEventRecord(ev_frame_done_, last_stream_)); // "the last frame has finished", for the load stream
 	if (snapshot_pending_) {
 		BM_HIP(hipEventSynchronize(ev_snapshot_));
 		snapshot_pending_ = false;
@@ -442,7 +442,7 @@ int Scene::process_load_queue(uint32_t* serviced) {
 			if (serviced) *serviced = count;
 		}
 	}
-	if (launches_ > 0) BM_HIP(hipStreamWaitEvent(load_stream_, ev_frame_done_, 0));
+	if (any_frame()) BM_HIP(hipStreamWaitEvent(load_stream_, ev_frame_done_, 0));
 	const int ring = ring_cur_;
 	BM_HIP(hipMemcpyAsync(h_count_[ring], d_load_count_[ring], sizeof(uint32_t), hipMemcpyDeviceToHost, load_stream_));
 	BM_HIP(hipMemcpyAsync(h_positions_[ring], d_load_queue_[ring], static_cast<size_t>(queue_cap_) * 3 * sizeof(int), hipMemcpyDeviceToHost, load_stream_));
@@ -531,6 +531,23 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 	launches_++;
 	last_stream_ = stream;
 	return 0;
+}
+
+int Scene::begin_frame(hipStream_t stream, DeviceScene* view, DeviceCounters** counters) {
+	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
+	BM_HIP(hipSetDevice(device_));
+	if (upload_pending_) { // bricks uploaded on the load stream must be visible to this frame
+		BM_HIP(hipStreamWaitEvent(stream, ev_upload_, 0));
+		upload_pending_ = false;
+	}
+	if (view) *view = view_;
+	if (counters) *counters = d_counters_;
+	return 0;
+}
+
+void Scene::end_frame(hipStream_t stream) {
+	other_frames_++;
+	last_stream_ = stream;
 }
 
 int Scene::resolve(const float* accum, float* out, long long n, hipStream_t stream) {

@@ -51,6 +51,12 @@ public:
 	int counters_reset();
 	int sched_stats_read(bm_sched_stats* out);
 
+	// Hooks for a frame issued by other code on this scene (the wavefront mode): begin_frame orders `stream` behind
+	// pending brick uploads and hands out the current device view; end_frame records the stream for process_load_queue.
+	int begin_frame(hipStream_t stream, DeviceScene* view, DeviceCounters** counters);
+	void end_frame(hipStream_t stream);
+	int compute_units() const { return compute_units_; }
+
 	World world;
 	int device() const { return device_; }
 
@@ -68,7 +74,9 @@ private:
 	static constexpr int kTimingRing = 256; // hipEvent pairs around the most recent render launches
 	hipEvent_t ev_start_[kTimingRing] = {}, ev_stop_[kTimingRing] = {};
 	hipEvent_t ev_upload_ = nullptr;
-	long long launches_ = 0;
+	long long launches_ = 0;       // render() launches (index into the timing ring)
+	long long other_frames_ = 0;   // frames issued through begin_frame / end_frame
+	bool any_frame() const { return launches_ + other_frames_ > 0; }
 	bool upload_pending_ = false;
 	hipStream_t last_stream_ = nullptr;
 

@@ -1,0 +1,492 @@
+// traverse.h -- device-side building blocks shared by the path-trace kernels (trace.hip: fused per-pixel paths;
+// wavefront.hip: the reference's queue-based extend / shade / connect schedule): GLM-order vector helpers, the
+// xorshift RNG, the brick-grid / 8^3 / 2^3 DDA of src/voxel.cuh, the sky model of src/sunsky.cu.
+// Per-ray arithmetic follows the reference operation for operation (IEEE fp32, no contraction; DESIGN.md "Numeric
+// contract"), so every kernel built from these pieces produces hits bit-identical to the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "detmath.h"
+#include "device_types.h"
+
+namespace bm {
+
+namespace {
+
+constexpr float kPi = 3.1415926535897932f;       // variables.h:3
+constexpr float kEpsilon = 0.001f;               // variables.h:22
+constexpr uint32_t kIndexBits = 0xFFFu;          // variables.h:29-33
+constexpr uint32_t kLodBits = 0xFF000u;
+constexpr uint32_t kLoadedBit = 0x80000000u;
+constexpr uint32_t kUnloadedBit = 0x40000000u;
+constexpr uint32_t kRequestedBit = 0x20000000u;
+
+struct f3 {
+	float x, y, z;
+};
+__device__ __forceinline__ f3 mk(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator/(f3 a, f3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }
+// GLM forms: min(a,b) = (b<a)?b:a, max(a,b) = (a<b)?b:a, sign(x) = (0<x)-(x<0)
+__device__ __forceinline__ float gmin(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float gmax(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ int isign(float x) { return (0.f < x) - (x < 0.f); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 x, f3 y) {
+	return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+__device__ __forceinline__ f3 normalize(f3 v) { return v * (1.0f / sqrtf(dot(v, v))); }
+__device__ __forceinline__ f3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+
+// ---- RNG (kernel.cu:19-37)
+__device__ __forceinline__ uint32_t random_int(uint32_t& seed) {
+	seed ^= seed << 13;
+	seed ^= seed >> 17;
+	seed ^= seed << 5;
+	return seed;
+}
+__device__ __forceinline__ float random_float(uint32_t& seed) { return random_int(seed) * 2.3283064365387e-10f; }
+__device__ __forceinline__ float random_float2(uint32_t& seed) { return (random_int(seed) >> 16) / 65535.0f; }
+
+// per-thread traversal counters (instrumented variant only)
+struct Tally {
+	uint32_t index_loads = 0, brick_tests = 0, byte_tests = 0, voxel_steps = 0, extend_rays = 0, shadow_rays = 0, requests = 0, paths = 0;
+};
+struct HitInfo {
+	int level = 0, brick_id = -1, sub_id = 0;
+};
+
+// ---- 8^3 bitmask DDA (voxel.cuh:79-133) and 2^3 LoD DDA (voxel.cuh:26-77): one body, N = 8 or 2.
+// `brick` holds the 64-byte brick (N == 8); `byte` is the LoD mask from the index word (N == 2).
+// The brick is fetched once, as four 16-byte loads in flight together, and staged in LDS: a z-slice of the
+// brick is exactly one 64-bit word (bit x + 8y), re-read only when the walk changes z.
+struct BrickRegs {
+	uint4 q0, q1, q2, q3;
+};
+
+// Brick staging in LDS: the 64-byte bitmask of the brick under test is written to the workgroup's LDS once and the
+// walk re-reads one 8-byte z-slice whenever it changes z.  Slice z of thread t lives at lds_brick[z * 256 + t]:
+// consecutive lanes hit consecutive 8-byte slots, so the eight stores and the per-z-move loads are free of bank
+// conflicts whatever z each lane wants (a 14-instruction register select tree per z-move measured 5 % slower).
+__device__ __forceinline__ void brick_to_lds(unsigned long long* lds_brick, const BrickRegs& b) {
+	const int t = threadIdx.x;
+	lds_brick[0 * 256 + t] = static_cast<unsigned long long>(b.q0.x) | (static_cast<unsigned long long>(b.q0.y) << 32);
+	lds_brick[1 * 256 + t] = static_cast<unsigned long long>(b.q0.z) | (static_cast<unsigned long long>(b.q0.w) << 32);
+	lds_brick[2 * 256 + t] = static_cast<unsigned long long>(b.q1.x) | (static_cast<unsigned long long>(b.q1.y) << 32);
+	lds_brick[3 * 256 + t] = static_cast<unsigned long long>(b.q1.z) | (static_cast<unsigned long long>(b.q1.w) << 32);
+	lds_brick[4 * 256 + t] = static_cast<unsigned long long>(b.q2.x) | (static_cast<unsigned long long>(b.q2.y) << 32);
+	lds_brick[5 * 256 + t] = static_cast<unsigned long long>(b.q2.z) | (static_cast<unsigned long long>(b.q2.w) << 32);
+	lds_brick[6 * 256 + t] = static_cast<unsigned long long>(b.q3.x) | (static_cast<unsigned long long>(b.q3.y) << 32);
+	lds_brick[7 * 256 + t] = static_cast<unsigned long long>(b.q3.z) | (static_cast<unsigned long long>(b.q3.w) << 32);
+}
+
+template <int N, bool DBG>
+__device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy, int sz, float dx, float dy, float dz, f3& normal, float& distance,
+											   const BrickRegs& brick, uint32_t byte, int& sub_id, Tally& tally, unsigned long long* lds_brick = nullptr) {
+	int px = static_cast<int>(origin.x), py = static_cast<int>(origin.y), pz = static_cast<int>(origin.z);
+	const float cbx = dir.x > 0.f ? static_cast<float>(px + 1) : static_cast<float>(px);
+	const float cby = dir.y > 0.f ? static_cast<float>(py + 1) : static_cast<float>(py);
+	const float cbz = dir.z > 0.f ? static_cast<float>(pz + 1) : static_cast<float>(pz);
+	// rdinv = sign * |1/d| exactly (0 for d == 0)
+	const float rx = static_cast<float>(sx) * dx, ry = static_cast<float>(sy) * dy, rz = static_cast<float>(sz) * dz;
+	float tx = dir.x != 0.f ? (cbx - origin.x) * rx : 1000000.f;
+	float ty = dir.y != 0.f ? (cby - origin.y) * ry : 1000000.f;
+	float tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
+	px %= N; py %= N; pz %= N;
+	distance = 0.f;
+	int axis = -1;
+	// "& 7" / "& 63" only define what the reference leaves undefined (a negative start cell); no effect otherwise
+	if (N == 8) brick_to_lds(lds_brick, brick);
+	unsigned long long slice = N == 8 ? lds_brick[(pz & 7) * 256 + threadIdx.x] : 0ull;
+	// at most 3N-2 cells lie on a line through an N^3 block; the bound only guards against NaN input
+	bool found = false;
+	for (int guard = 0; guard < 3 * N + 2; ++guard) {
+		if (DBG) tally.voxel_steps++;
+		bool solid;
+		if (N == 8) solid = (slice >> ((px + py * 8) & 63)) & 1ull;
+		else solid = (byte >> ((px + py * 2 + pz * 4) & 31)) & 1u;
+		if (solid) { found = true; break; } // resolved after the loop, once, for all lanes that hit
+		// select-style move (voxel.cuh:122-130); `t += mask ? delta : 0` is `tmax += mask * tdelta` for finite deltas
+		const bool mx = tx < ty && tx < tz;
+		const bool my = ty <= tx && ty < tz; // mx implies !my
+		const bool mz = !(mx || my);
+		axis = mx ? 0 : (my ? 1 : 2);
+		px += mx ? sx : 0;
+		py += my ? sy : 0;
+		pz += mz ? sz : 0;
+		const int c = mx ? px : (my ? py : pz);
+		const int s_sel = mx ? sx : (my ? sy : sz);
+		if (c == (s_sel > 0 ? N : -1)) break; // left the block
+		tx += mx ? dx : 0.f;
+		ty += my ? dy : 0.f;
+		tz += mz ? dz : 0.f;
+		if (N == 8 && mz) slice = lds_brick[pz * 256 + threadIdx.x];
+	}
+	if (!found) return false;
+	if (axis > -1) { // voxel.cuh:114-118; a hit in the very first cell keeps distance 0 and the caller's normal
+		normal = mk(axis == 0 ? -static_cast<float>(sx) : 0.f, axis == 1 ? -static_cast<float>(sy) : 0.f, axis == 2 ? -static_cast<float>(sz) : 0.f);
+		distance = axis == 0 ? tx - dx : (axis == 1 ? ty - dy : tz - dz);
+	}
+	sub_id = px + py * N + pz * N * N;
+	return true;
+}
+
+// ---- brick-grid DDA (voxel.cuh:135-261), split into the three pieces the wave scheduler interleaves
+//
+// The reference reads one 32-bit index word per visited cell (two dependent loads through its pointer
+// table).  ~96 % of those words are zero (air), so the walk consults a two-level occupancy summary kept
+// in registers -- a 64-bit mask of the current 4x4x4-brick block and a 64-bit mask of the current
+// supercell's blocks (DeviceScene) -- and touches the index grid only at cells known to be non-empty.
+// Masks are re-read only when the walk crosses a block / supercell boundary, and because the world edge
+// is a supercell boundary the reference's per-step exit test (voxel.cuh:256) moves into that rare path too.
+// The per-cell arithmetic (axis choice, tmax accumulation) is the reference's, step for step.
+struct RayState {
+	f3 o, d;            // origin (brick units once set up) and direction
+	float tx, ty, tz;   // tmax
+	float dx, dy, dz;   // tdelta = |1/d|
+	int px, py, pz;     // current brick cell
+	int sx, sy, sz;     // step signs
+	float tminn;
+	f3 n;               // normal carried in/out of the traversal (voxel.cuh:135 `normal`)
+	int axis;           // axis of the last move, -1 before the first
+	unsigned long long coarse, fine;
+	uint32_t block_base; // arena slot of the current block's first brick
+	int sci;
+	float distance;     // result
+	bool hit;
+};
+
+enum : int { ST_NEED = 0, ST_OUTER = 1, ST_CAND = 2, ST_FIN = 3 };
+
+__device__ __forceinline__ void load_super(const DeviceScene& sc, RayState& r) {
+	r.sci = (r.px >> 4) + (r.py >> 4) * sc.sg_xy + (r.pz >> 4) * sc.sg_xy2;
+	const uint2 rec = *reinterpret_cast<const uint2*>(sc.super_info + r.sci);
+	r.coarse = static_cast<unsigned long long>(rec.x) | (static_cast<unsigned long long>(rec.y) << 32);
+}
+__device__ __forceinline__ void load_block(const DeviceScene& sc, RayState& r) {
+	const int bi = ((r.px >> 2) & 3) + (((r.py >> 2) & 3) << 2) + (((r.pz >> 2) & 3) << 4);
+	r.fine = 0ull;
+	if ((r.coarse >> bi) & 1ull) {
+		const uint4 rec = *reinterpret_cast<const uint4*>(sc.block_info + (static_cast<size_t>(r.sci) << 6) + bi);
+		r.fine = static_cast<unsigned long long>(rec.x) | (static_cast<unsigned long long>(rec.y) << 32);
+		r.block_base = rec.z;
+	}
+}
+__device__ __forceinline__ bool cell_occupied(const RayState& r) {
+	const int ci = (r.px & 3) + ((r.py & 3) << 2) + ((r.pz & 3) << 4);
+	return (r.fine >> ci) & 1ull;
+}
+
+// voxel.cuh:136-189: clip against the world box, move onto it, set up the Amanatides-Woo state.
+// Returns the lane's next state: ST_OUTER / ST_CAND, or ST_NEED with r.hit = false when the ray misses the box.
+template <bool DBG>
+__device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const f3 dir, RayState& r, Tally& tally) {
+	r.hit = false;
+	r.d = dir;
+	// intersect_aabb_branchless2 (voxel.cuh:13-24).  For an origin strictly inside the box every slab entry time is
+	// negative and every exit time positive, so the reference's result is exactly (true, tmin = 0): the six IEEE
+	// divisions are only needed for rays that start on or outside the boundary.
+	float tminn = 0.f;
+	const bool inside = origin.x > 0.f && origin.x < sc.grid_size_f && origin.y > 0.f && origin.y < sc.grid_size_f && origin.z > 0.f &&
+						origin.z < sc.grid_height_f && (dir.x != 0.f || dir.y != 0.f || dir.z != 0.f) &&
+						dir.x == dir.x && dir.y == dir.y && dir.z == dir.z; // NaN directions (bounce off a zero normal) take the full test
+	if (!inside) {
+		const f3 t1 = (mk(0.f, 0.f, 0.f) - origin) / dir;
+		const f3 t2 = (mk(sc.grid_size_f, sc.grid_size_f, sc.grid_height_f) - origin) / dir;
+		const f3 tMin = mk(gmin(t1.x, t2.x), gmin(t1.y, t2.y), gmin(t1.z, t2.z));
+		const f3 tMax = mk(gmax(t1.x, t2.x), gmax(t1.y, t2.y), gmax(t1.z, t2.z));
+		tminn = gmax(gmax(tMin.x, 0.f), gmax(tMin.y, tMin.z));
+		if (!(gmin(tMax.x, gmin(tMax.y, tMax.z)) > tminn)) return ST_NEED;
+	}
+	r.tminn = tminn;
+	if (tminn > 0) { // move the ray onto the box and derive the entry-face normal (voxel.cuh:142-155)
+		origin = origin + dir * tminn;
+		const float gs = sc.grid_size_f, gh = sc.grid_height_f;
+		const f3 scale = mk(1.f / (gs / gh), 1.f / (gs / gh), 1.f / (gh / gh));
+		const f3 center = mk(gs / 2.f, gs / 2.f, gh / 2.f);
+		const f3 d = center - origin;
+		f3 to_center = mk(fabsf(d.x), fabsf(d.y), fabsf(d.z)) * scale;
+		const f3 e = origin - center;
+		const f3 signs = mk(static_cast<float>(isign(e.x)), static_cast<float>(isign(e.y)), static_cast<float>(isign(e.z)));
+		to_center = to_center / gmax(to_center.x, gmax(to_center.y, to_center.z));
+		r.n = signs * mk(truncf(to_center.x + 0.000001f), truncf(to_center.y + 0.000001f), truncf(to_center.z + 0.000001f));
+		origin = origin - r.n * kEpsilon;
+	}
+	origin = origin / 8.f;
+	r.o = origin;
+	r.px = static_cast<int>(origin.x); r.py = static_cast<int>(origin.y); r.pz = static_cast<int>(origin.z);
+	const int cells = sc.cells, cells_h = sc.cells_height;
+	if (r.px < 0 || r.px >= cells || r.py < 0 || r.py >= cells || r.pz < 0 || r.pz >= cells_h) return ST_NEED;
+	const float cbx = dir.x > 0.f ? static_cast<float>(r.px + 1) : static_cast<float>(r.px);
+	const float cby = dir.y > 0.f ? static_cast<float>(r.py + 1) : static_cast<float>(r.py);
+	const float cbz = dir.z > 0.f ? static_cast<float>(r.pz + 1) : static_cast<float>(r.pz);
+	r.sx = isign(dir.x); r.sy = isign(dir.y); r.sz = isign(dir.z);
+	const float rx = dir.x == 0.0f ? 0.0f : 1.f / dir.x;
+	const float ry = dir.y == 0.0f ? 0.0f : 1.f / dir.y;
+	const float rz = dir.z == 0.0f ? 0.0f : 1.f / dir.z;
+	r.tx = dir.x != 0.f ? (cbx - origin.x) * rx : 1000000.f;
+	r.ty = dir.y != 0.f ? (cby - origin.y) * ry : 1000000.f;
+	r.tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
+	r.dx = static_cast<float>(r.sx) * rx; r.dy = static_cast<float>(r.sy) * ry; r.dz = static_cast<float>(r.sz) * rz;
+	r.axis = -1;
+	load_super(sc, r);
+	load_block(sc, r);
+	if (DBG) tally.index_loads++; // one per visited cell = the reference's index loads (algorithmic count)
+	return cell_occupied(r) ? ST_CAND : ST_OUTER;
+}
+
+// voxel.cuh:249-258: one Amanatides-Woo move to the next cell.  Returns the next state.
+// Written select-style (no per-axis branches): the only divergent region is the block / supercell
+// boundary crossing.  `t += mask ? delta : 0` is the reference's `tmax += mask * tdelta` for finite deltas.
+template <bool DBG>
+__device__ __forceinline__ int outer_step(const DeviceScene& sc, RayState& r, Tally& tally) {
+	// work on scalar copies: selects between struct members would otherwise pin the struct in scratch memory
+	const float tx = r.tx, ty = r.ty, tz = r.tz;
+	const int sx = r.sx, sy = r.sy, sz = r.sz;
+	const bool mx = tx < ty && tx < tz;
+	const bool my = ty <= tx && ty < tz; // mx implies !my
+	const bool mz = !(mx || my);
+	const int npx = r.px + (mx ? sx : 0);
+	const int npy = r.py + (my ? sy : 0);
+	const int npz = r.pz + (mz ? sz : 0);
+	r.px = npx; r.py = npy; r.pz = npz;
+	r.tx = tx + (mx ? r.dx : 0.f);
+	r.ty = ty + (my ? r.dy : 0.f);
+	r.tz = tz + (mz ? r.dz : 0.f);
+	r.axis = mx ? 0 : (my ? 1 : 2);
+	const int s_sel = mx ? sx : (my ? sy : sz);
+	const int c = mx ? npx : (my ? npy : npz);
+	// a move along -axis crosses a 4- / 16-aligned boundary when the NEW coordinate + 1 is aligned
+	const int ce = c - (s_sel >> 31);
+	if ((ce & 3) == 0) {
+		if ((ce & 15) == 0) {
+			// supercell boundary; the world edge is one of them, so the exit test (voxel.cuh:256) lives here
+			const int lim = mz ? sc.cells_height : sc.cells;
+			if (c == (s_sel > 0 ? lim : -1)) return ST_NEED; // left the grid: miss (r.hit stays false)
+			load_super(sc, r);
+		}
+		load_block(sc, r);
+	}
+	if (DBG) tally.index_loads++;
+	return cell_occupied(r) ? ST_CAND : ST_OUTER;
+}
+
+// voxel.cuh:200-247: the current cell holds a non-empty brick -- read its index word and resolve it.
+template <bool DBG>
+__device__ __forceinline__ int process_candidate(const DeviceScene& sc, const int* campos, RayState& r, HitInfo& info, Tally& tally,
+													 unsigned long long* lds_brick) {
+	const int px = r.px, py = r.py, pz = r.pz;
+	// inside the grid 0 <= pos < cells, so >>4 and &15 equal the reference's signed /16 and %16
+	const uint32_t flat = (static_cast<uint32_t>(r.sci) << 12) + static_cast<uint32_t>((px & 15) + ((py & 15) << 4) + ((pz & 15) << 8));
+	// Home slot of this brick: block base + rank of its bit in the block mask.  It does not depend on the index
+	// word, so the 64-byte brick read is issued together with the index-word read instead of behind it (every
+	// non-empty cell owns its slot whether or not the brick is resident, so the read is always in bounds).
+	const int ci = (px & 3) + ((py & 3) << 2) + ((pz & 3) << 4);
+	const uint32_t slot = r.block_base + static_cast<uint32_t>(__popcll(r.fine & ((1ull << ci) - 1ull)));
+	const uint4* bq = reinterpret_cast<const uint4*>(sc.brick_arena + (static_cast<size_t>(slot) << 4));
+	const uint32_t index = sc.index_grid[flat];
+	BrickRegs brick;
+	brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
+	float new_distance = 0.f;
+	if (r.axis != -1) {
+		r.n = mk(0.f, 0.f, 0.f);
+		if (r.axis == 0) { r.n.x = -static_cast<float>(r.sx); new_distance = r.tx - r.dx; }
+		else if (r.axis == 1) { r.n.y = -static_cast<float>(r.sy); new_distance = r.ty - r.dy; }
+		else { r.n.z = -static_cast<float>(r.sz); new_distance = r.tz - r.dz; }
+	}
+	const int ddx = campos[0] - px, ddy = campos[1] - py, ddz = campos[2] - pz;
+	const int lod2 = ddx * ddx + ddy * ddy + ddz * ddz;
+	float sub_distance = 0.f;
+	if (DBG) info.brick_id = px + py * sc.cells + pz * sc.cells * sc.cells;
+	if (lod2 > sc.lod_distance_8x8x8) {
+		r.distance = new_distance * 8.f + r.tminn;
+		if (DBG) { info.level = 0; info.sub_id = 0; }
+		r.hit = true;
+		return ST_NEED;
+	} else if (lod2 > sc.lod_distance_2x2x2) {
+		if (DBG) tally.byte_tests++;
+		int sub = 0;
+		const f3 o2 = (r.o + r.d * new_distance) * 2.f - r.n * 0.2f * kEpsilon;
+		if (intersect_grid<2, DBG>(o2, r.d, r.sx, r.sy, r.sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, (index & kLodBits) >> 12, sub, tally)) {
+			r.distance = new_distance * 8.f + sub_distance * 4.f + r.tminn;
+			if (DBG) { info.level = 1; info.sub_id = sub; }
+			r.hit = true;
+			return ST_NEED;
+		}
+	} else if (index & kLoadedBit) {
+		if (DBG) tally.brick_tests++;
+		int sub = 0;
+		const f3 o8 = (r.o + r.d * new_distance) * 8.f - r.n * kEpsilon;
+		if (intersect_grid<8, DBG>(o8, r.d, r.sx, r.sy, r.sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick)) {
+			r.distance = new_distance * 8.f + sub_distance + r.tminn;
+			if (DBG) { info.level = 2; info.sub_id = sub; }
+			r.hit = true;
+			return ST_NEED;
+		}
+	} else if (index & kUnloadedBit) {
+		// brick-request protocol (voxel.cuh:228-245): 32-bit atomics on the index word and the ring counter
+		const uint32_t old = atomicOr(&sc.index_grid[flat], kRequestedBit);
+		if (!(old & kRequestedBit)) {
+			const uint32_t load_index = atomicAdd(sc.load_queue_count, 1u);
+			if (load_index < sc.queue_cap) {
+				int* q = sc.load_queue + 3 * static_cast<size_t>(load_index);
+				q[0] = px; q[1] = py; q[2] = pz;
+				if (DBG) tally.requests++;
+			} else {
+				atomicAnd(&sc.index_grid[flat], ~kRequestedBit);
+			}
+		}
+		r.distance = new_distance * 8.f + r.tminn;
+		if (DBG) { info.level = 3; info.sub_id = 0; }
+		r.hit = true;
+		return ST_NEED;
+	}
+	return ST_OUTER; // nothing solid along the ray inside this brick: keep walking
+}
+
+// ---- sky model (sunsky.cu:10-161); view-independent terms arrive precomputed in FrameConstants.
+// Split so that lanes shading a sun sample (sun()) and lanes shading a miss (sky() / sunsky()) share the
+// extinction term.  RayleighPhase / hgPhase (sunsky.cu:10-12,20-22) contain double literals in the
+// reference; they are evaluated in fp32 here (difference ~1e-6 relative, inside the 1e-4 radiance bar).
+struct SkyView {
+	f3 Fex;           // combined extinction factor
+	float cosViewSun;
+};
+__device__ __forceinline__ SkyView sky_view(const FrameConstants& fc, f3 viewDir) {
+	SkyView o;
+	o.cosViewSun = dot(viewDir, ld3(fc.sun_direction));
+	const float cosUpView = dot(mk(0.f, 0.f, 1.f), viewDir);
+	const float zenith = gmax(0.0f, cosUpView);
+	const float rayleighLen = 8.4E3f / zenith;
+	const float mieLen = 1.25E3f / zenith;
+	const f3 a = ld3(fc.rayleigh) * rayleighLen + ld3(fc.mie) * mieLen;
+	o.Fex = mk(expf(-a.x), expf(-a.y), expf(-a.z));
+	return o;
+}
+// in-scattered sky light: `sky` of sunsky.cu:109-111 (before the 0.01 / SkyFactor scaling)
+__device__ __forceinline__ f3 sky_scatter(const FrameConstants& fc, const SkyView& v) {
+	const float c = v.cosViewSun;
+	const float rayleighPhase = (3.0f / (16.0f * kPi)) * (1.0f + c * c);
+	const float g = 0.80f, g2 = 0.80f * 0.80f;
+	const float base = 1.0f - 2.0f * g * c + g2;
+	const float hg = (1.0f / (4.0f * kPi)) * ((1.0f - g2) / (base * sqrtf(base)));
+	const f3 light = ld3(fc.rayleigh) * rayleighPhase + ld3(fc.mie) * hg;
+	const f3 somethingElse = (light / ld3(fc.total)) * fc.sunE;
+	const f3 sky = somethingElse * mk(1.0f - v.Fex.x, 1.0f - v.Fex.y, 1.0f - v.Fex.z);
+	const f3 q = somethingElse * v.Fex;
+	const f3 p = mk(sqrtf(q.x), sqrtf(q.y), sqrtf(q.z)); // pow(x, 0.5)
+	const float a = fc.mixf;
+	return sky * mk(1.0f * (1.0f - a) + p.x * a, 1.0f * (1.0f - a) + p.y * a, 1.0f * (1.0f - a) + p.z * a);
+}
+__device__ __forceinline__ f3 sun_from_view(const FrameConstants& fc, const SkyView& v) { // sun(), sunsky.cu:32-74
+	// quirk kept: `sunAngularDiameterCos < (cosViewSunAngle ? 1.0 : 0.0)` tests cos != 0
+	const float sundisk = static_cast<double>(fc.sun_angular_cos) < (v.cosViewSun != 0.0f ? 1.0 : 0.0) ? 1.0f : 0.0f;
+	return ((v.Fex * (fc.sunE * 19000.0f)) * sundisk) * 0.01f;
+}
+__device__ __forceinline__ f3 sky_from_view(const FrameConstants& fc, const SkyView& v) { // sky(), sunsky.cu:76-114
+	return sky_scatter(fc, v) * (1.f * 0.01f);
+}
+__device__ __forceinline__ f3 sunsky_from_view(const FrameConstants& fc, const SkyView& v) { // sunsky(), sunsky.cu:116-161
+	const f3 sky = sky_scatter(fc, v);
+	const float e0 = fc.sun_angular_cos, e1 = fc.sun_angular_cos + 0.00002f;
+	const float s = gmin(gmax((v.cosViewSun - e0) / (e1 - e0), 0.0f), 1.0f);
+	const float sundisk = s * s * (3.0f - 2.0f * s);
+	const f3 sun = ((v.Fex * (fc.sunE * 19000.0f)) * sundisk) * 1E-5f;
+	return (sun + sky) * 0.01f;
+}
+__device__ __forceinline__ f3 sun_radiance(const FrameConstants& fc, f3 viewDir) { return sun_from_view(fc, sky_view(fc, viewDir)); }
+__device__ __forceinline__ f3 sky_radiance(const FrameConstants& fc, f3 viewDir) { return sky_from_view(fc, sky_view(fc, viewDir)); }
+__device__ __forceinline__ f3 sunsky_radiance(const FrameConstants& fc, f3 viewDir) {
+	if (fc.sun_angular_cos == 1.0f) return mk(1.0f, 0.0f, 0.0f); // sunsky.cu:121-123
+	return sunsky_from_view(fc, sky_view(fc, viewDir));
+}
+
+// getConeSample(sunDirection, extent, seed) (sunsky.cu:163-183).  Its orthonormal frame depends only on the
+// sun direction, so normalize(dir), o1 and o2 arrive precomputed (same fp32 operations, done once on the host).
+__device__ __forceinline__ f3 cone_sample(const FrameConstants& fc, uint32_t& seed) {
+	const f3 dir = ld3(fc.cone_dir), o1 = ld3(fc.cone_o1), o2 = ld3(fc.cone_o2);
+	float rx = random_float2(seed);
+	float ry = random_float2(seed);
+	rx = rx * 2.f * kPi;
+	ry = 1.0f - ry * fc.cone_extent;
+	const float oneminus = sqrtf(1.0f - ry * ry);
+	float s, c;
+	det_sincos(rx, s, c);
+	return (o1 * (c * oneminus) + o2 * (s * oneminus)) + dir * ry;
+}
+
+// primary_rays (kernel.cu:157-200): camera ray through pixel (x, y) for the RNG stream `seed`.
+// Random2DStratifiedSample (kernel.cu:40-61), ConcentricSampleDisk (kernel.cu:85-103); lens sample drawn left to right.
+__device__ __forceinline__ void primary_ray(const FrameConstants& fc, uint32_t seed, uint32_t x, uint32_t y, f3& origin, f3& direction) {
+	const f3 cam_right = ld3(fc.right), cam_up = ld3(fc.up), cam_dir = ld3(fc.dir), cam_o = ld3(fc.origin);
+	const float W = static_cast<float>(static_cast<uint32_t>(fc.width)), H = static_cast<float>(static_cast<uint32_t>(fc.height));
+	const int stratum = static_cast<int>(random_float(seed) * (16 + 0.99999f));
+	const int stratumX = stratum % 4, stratumY = (stratum / 4) % 4;
+	const float jx = 0.25f * stratumX + (random_float(seed) * 0.25f);
+	const float jy = 0.25f * stratumY + (random_float(seed) * 0.25f);
+	const float ppx = static_cast<float>(x) - jx;
+	const float ppy = static_cast<float>(y) - jy;
+	const float ni = (ppx / W) - 0.5f;
+	const float nj = ((H - ppy) / H) - 0.5f;
+	const f3 to_focal = normalize(cam_dir + cam_right * ni + cam_up * nj);
+	const f3 convergence = cam_o + to_focal * fc.focal3;
+	origin = cam_o;
+	if (fc.lens_radius != 0.f) {
+		// with lens radius 0 the reference multiplies the disk sample by 0 and nothing reads this seed again: draws skipped
+		const float l0 = random_float(seed);
+		const float l1 = random_float(seed);
+		float lx = 0.f, ly = 0.f;
+		const float ox = 2.f * l0 - 1.f, oy = 2.f * l1 - 1.f;
+		if (!(ox == 0 && oy == 0)) {
+			float theta, rr;
+			if (fabsf(ox) > fabsf(oy)) { rr = ox; theta = kPi / 4 * (oy / ox); }
+			else { rr = oy; theta = kPi / 2 - kPi / 4 * (ox / oy); }
+			float sn, cs;
+			det_sincos(theta, sn, cs);
+			lx = rr * cs;
+			ly = rr * sn;
+		}
+		const float plx = fc.lens_radius * lx, ply = fc.lens_radius * ly;
+		origin = cam_o + cam_right * plx + cam_up * ply;
+	}
+	direction = normalize(convergence - origin);
+}
+
+// cosine-weighted bounce direction of shade() (kernel.cu:281-297), RNG stream continued from the cone sample
+__device__ __forceinline__ f3 bounce_direction(f3 n, uint32_t& seed) {
+	const float r1 = 2.f * kPi * random_float(seed);
+	const float r2 = random_float(seed);
+	const float r2s = sqrtf(r2);
+	// computeOrthonormalBasisNaive (kernel.cu:76-84)
+	f3 u = fabs(static_cast<double>(n.x)) > .9 ? mk(0.0f, 1.0f, 0.0f) : mk(1.0f, 0.0f, 0.0f);
+	u = normalize(cross(u, n));
+	const f3 v = cross(n, u);
+	float sn, cs;
+	det_sincos(r1, sn, cs);
+	return normalize(((u * cs) * r2s + (v * sn) * r2s) + n * sqrtf(1 - r2));
+}
+
+// hit-record hashing, identical to oracle.c (hmix / pack_normal)
+__device__ __forceinline__ uint32_t hmix(uint32_t h, uint32_t v) {
+	h ^= v;
+	h *= 16777619u;
+	h ^= h >> 15;
+	return h;
+}
+__device__ __forceinline__ uint32_t pack_normal(f3 n) {
+	const float c[3] = {n.x, n.y, n.z};
+	uint32_t r = 0;
+	for (int i = 0; i < 3; i++) {
+		const uint32_t code = c[i] == 0.0f ? 0u : (c[i] == 1.0f ? 1u : (c[i] == -1.0f ? 2u : 3u));
+		r |= code << (2 * i);
+	}
+	return r;
+}
+
+} // namespace
+
+} // namespace bm

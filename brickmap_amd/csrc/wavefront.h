@@ -1,0 +1,40 @@
+// wavefront.h -- host side of the wavefront mode: the queues and per-call orchestration of the reference's
+// launch_kernels (src/kernel.cu:366-439) with its static / __device__ state (frame, start_position,
+// primary_ray_cnt; kernel.cu:106-119,369) held per object instead of in globals.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "scene.h"
+
+namespace bm {
+
+class Wavefront {
+public:
+	Wavefront(Scene* scene, uint32_t queue_size) : scene_(scene), queue_size_(queue_size) {}
+	~Wavefront();
+	int init();
+	int reset(); // the reset_buffer branch of launch_kernels (:397-403): primary_ray_cnt = 0; the caller zeroes the frame buffer
+	int frame(const bm_camera* cam, const bm_frame_params* fp, float* accum, hipStream_t stream);
+	int stats(uint32_t* out6);
+	int read_queue(int which, uint32_t first, uint32_t count, void* host_out);
+	int times(float* ms5);
+
+private:
+	Scene* scene_;
+	uint32_t queue_size_;
+	uint32_t frame_ = 1; // kernel.cu:369
+	bool reset_pending_ = false;
+	WfRay* d_work_ = nullptr;   // ray_buffer_work / ray_buffer_next (state.h:19-20), swapped after every frame (main.cpp:146)
+	WfRay* d_next_ = nullptr;
+	WfShadow* d_shadow_ = nullptr;
+	WfState* d_state_ = nullptr;
+	void* d_block_counts_ = nullptr;
+	static constexpr int kConstantsRing = 64;
+	FrameConstants* d_frame_constants_ = nullptr;
+	FrameConstants* h_frame_constants_ = nullptr;
+	hipEvent_t ev_[5] = {};
+	bool timed_ = false;
+	int blocks_per_cu_[2][2] = {{0, 0}, {0, 0}}; // [connect][instrumented]
+};
+
+} // namespace bm

@@ -278,6 +278,71 @@ class Scene:
         return out
 
 
+# numpy views of the queue records (variables.h:43-52 RayQueue, :54-59 ShadowQueue)
+RAY_QUEUE_DTYPE = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3), ("throughput", "<f4", 3), ("normal", "<f4", 3),
+                            ("distance", "<f4"), ("identifier", "<i4"), ("bounces", "<i4"), ("pixel_index", "<u4")])
+SHADOW_QUEUE_DTYPE = np.dtype([("origin", "<f4", 3), ("direction", "<f4", 3), ("color", "<f4", 3), ("pixel_index", "<u4")])
+
+
+class Wavefront:
+    """The reference's own schedule (kernel.cu:366-439): every `frame()` is one launch_kernels call -- primary_rays
+    tops the work queue up to `queue_size` (ray_queue_buffer_size, variables.h:61), extend, shade, connect, swap --
+    so a path needs max_bounces + 1 frames.  Holds what the reference keeps in statics / __device__ globals
+    (frame counter, start_position, primary_ray_cnt) and in State (the two ray queues and the shadow queue)."""
+
+    def __init__(self, scene: Scene, queue_size=2 * 1048576):
+        self._L = _lib.load()
+        self.scene, self.queue_size = scene, queue_size
+        self.handle = C.c_void_p()
+        check(self._L.bm_wavefront_create(scene.gpuScene, queue_size, C.byref(self.handle)))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._L.bm_wavefront_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    def reset(self):
+        """reset_buffer branch of launch_kernels (:397-403); the caller zeroes the accumulation buffer."""
+        check(self._L.bm_wavefront_reset(self.handle))
+
+    def frame(self, camera: Camera, params: FrameParams, accum, stream=None):
+        import torch
+        assert accum.is_cuda and accum.dtype == torch.float32 and accum.is_contiguous()
+        assert accum.numel() == params.width * params.height * 4, "accum must be [height, width, 4]"
+        if stream is None:
+            stream = torch.cuda.current_stream(accum.device).cuda_stream
+        cam_c, par_c = camera.to_c(), params.to_c()
+        check(self._L.bm_wavefront_frame(self.handle, C.byref(cam_c), C.byref(par_c), C.c_void_p(accum.data_ptr()), C.c_void_p(stream)))
+
+    def stats(self):
+        out = np.zeros(6, np.uint32)
+        check(self._L.bm_wavefront_stats(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return dict(survivors=int(out[0]), shadow=int(out[1]), start_position=int(out[2]), frame=int(out[3]),
+                    generated=int(out[4]), primary_ray_cnt=int(out[5]))
+
+    def read_queue(self, which, first=0, count=None):
+        """which = "work" (RayQueue records; the survivors of the last frame lead) or "shadow"."""
+        kind = {"work": 0, "shadow": 1}[which]
+        dtype = RAY_QUEUE_DTYPE if kind == 0 else SHADOW_QUEUE_DTYPE
+        if count is None:
+            count = self.queue_size - first
+        out = np.zeros(count, dtype)
+        check(self._L.bm_wavefront_read_queue(self.handle, kind, first, count, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def times(self):
+        """hipEvent durations (ms) of the last frame."""
+        ms = (C.c_float * 5)()
+        check(self._L.bm_wavefront_times(self.handle, ms))
+        return dict(total=ms[0], primary=ms[1], extend=ms[2], shade=ms[3], connect=ms[4])
+
+
 class State:
     """state.h:5-34 minus the wavefront queues and the GL interop: owns the float4 accumulation
     ("blit") buffer of this process' shard of the frame."""

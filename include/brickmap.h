@@ -174,6 +174,31 @@ BM_API int bm_counters_read(bm_scene* scene, bm_counters* out);
 BM_API int bm_counters_reset(bm_scene* scene);
 BM_API int bm_sched_stats_read(bm_scene* scene, bm_sched_stats* out);
 
+/* ---- wavefront mode: launch_kernels exactly as the reference schedules it (kernel.cu:366-439) --
+ * one call traces ONE segment of every path in flight: primary_rays tops the work queue up to `queue_size`
+ * (ray_queue_buffer_size, variables.h:61), extend, shade (survivors -> next queue, shadow rays -> shadow queue),
+ * connect; then the queues are swapped (main.cpp:146).  The reference's statics / __device__ globals (frame,
+ * start_position, primary_ray_cnt; kernel.cu:106-119,369) live in the bm_wavefront object.  Of `params` the
+ * fields width, height, max_bounces, sun_position and flags (BM_FLAG_COUNTERS) are used; the frame number is
+ * the object's own counter (starts at 1).  Survivors and shadow rays are compacted in slot order, i.e. the
+ * order a sequential run of the reference produces.  Single GPU: the queue schedule does not shard. */
+typedef struct bm_wavefront bm_wavefront;
+BM_API int bm_wavefront_create(bm_scene* scene, uint32_t queue_size, bm_wavefront** out);
+BM_API void bm_wavefront_destroy(bm_wavefront* wf);
+/* the reset_buffer branch of launch_kernels (:397-403): drop the paths in flight; the caller zeroes accum_dev */
+BM_API int bm_wavefront_reset(bm_wavefront* wf);
+BM_API int bm_wavefront_frame(bm_wavefront* wf, const bm_camera* camera, const bm_frame_params* params, float* accum_dev,
+                              void* hip_stream);
+/* out6 = survivors and shadow rays of the last frame, start_position, frame (next), primary rays generated by the
+ * last frame, primary_ray_cnt; blocks until the device is idle */
+BM_API int bm_wavefront_stats(bm_wavefront* wf, uint32_t* out6);
+/* copy queue records to the host: which = 0 the work queue (64-byte RayQueue records, variables.h:43-52; after a
+ * frame its first `survivors` slots hold the paths that continue), 1 the shadow queue (40-byte ShadowQueue records,
+ * variables.h:54-59; first `shadow` slots) */
+BM_API int bm_wavefront_read_queue(bm_wavefront* wf, int which, uint32_t first, uint32_t count, void* host_out);
+/* hipEvent durations (ms) of the last frame: total, primary_rays + globals, extend, shade, connect */
+BM_API int bm_wavefront_times(bm_wavefront* wf, float* ms5);
+
 /* ---- numeric-contract probes used by the parity tests (device side of detmath.h etc.) */
 BM_API int bm_debug_sincos(int device, int n, const float* x_host, float* sin_host, float* cos_host);
 BM_API int bm_debug_sky(int device, const float sun_position[2], int n, const float* viewdirs_host /*3n*/,

@@ -99,6 +99,7 @@ def lib():
             "orc_wavefront_reset": (None, [vp]),
             "orc_wavefront_stats": (None, [vp, vp]),
             "orc_wavefront_counters": (None, [vp, C.POINTER(Counters)]),
+            "orc_wavefront_read_queue": (C.c_int, [vp, C.c_int, C.c_uint, C.c_uint, vp]),
             "orc_wavefront_frame": (None, [vp, vp, C.POINTER(Camera), i, i, f, f, vp]),
             "orc_resolve": (None, [vp, vp, i]),
             "orc_sizeof_counters": (i, []),
@@ -265,6 +266,13 @@ class Wavefront:
         self.L.orc_wavefront_stats(self.h, _ptr(out))
         return dict(survivors=int(out[0]), shadow=int(out[1]), start_position=int(out[2]), frame=int(out[3]),
                     generated=int(out[4]), primary_ray_cnt=int(out[5]))
+
+    def read_queue(self, which, first, count):
+        """raw bytes of `count` records of the work (which=0, 64 B each) or shadow (which=1, 40 B each) queue"""
+        out = np.zeros(count * (64 if which == 0 else 40), np.uint8)
+        rc = self.L.orc_wavefront_read_queue(self.h, which, first, count, _ptr(out))
+        assert rc == 0
+        return out
 
     def counters(self):
         cnt = Counters()

@@ -1133,6 +1133,14 @@ ORC_API void orc_wavefront_reset(orc_wavefront* s) { s->primary_ray_cnt = 0; }
 ORC_API void orc_wavefront_stats(const orc_wavefront* s, unsigned* out6) {
 	out6[0] = s->last_survivors; out6[1] = s->last_shadow; out6[2] = s->start_position; out6[3] = s->frame; out6[4] = s->last_generated; out6[5] = s->primary_ray_cnt;
 }
+/* test door: copy records out of the work queue (which = 0; after a frame its first `survivors` slots hold the
+ * continuing paths) or the shadow queue (which = 1) */
+ORC_API int orc_wavefront_read_queue(const orc_wavefront* s, int which, unsigned first, unsigned count, void* out) {
+	if (first > s->queue_size || count > s->queue_size - first) return -1;
+	if (which == 0) memcpy(out, s->work + first, (size_t)count * sizeof(RayQueue));
+	else memcpy(out, s->shadow + first, (size_t)count * sizeof(ShadowQueue));
+	return 0;
+}
 ORC_API void orc_wavefront_counters(const orc_wavefront* s, orc_counters* out) { *out = s->cnt; }
 
 /* One call of launch_kernels (kernel.cu:366-439) followed by process_load_queue + swap (main.cpp:142-146). */
