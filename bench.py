@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--schedule", choices=["fused", "wavefront"], default="fused",
+                    help="fused = one persistent kernel tracing complete paths (the product's default); wavefront = the "
+                         "reference's own queue schedule, one segment of every path in flight per step (N = 1 only)")
     args = ap.parse_args()
 
     import numpy as np
@@ -97,6 +100,10 @@ def main():
     cam = bm.Camera(position=(G / 2, G / 8, 0.8 * G), horizontal_angle=0.8, vertical_angle=-0.5).update()
     state = bm.State(W, H, device=local_rank, band_rows=band, shard_rank=rank, shard_count=world)
     accum = state.blit_buffer
+    if args.schedule == "wavefront":
+        if world != 1:
+            raise SystemExit("--schedule wavefront does not shard (replicas only): run it with --gpus 1")
+        return bench_wavefront(args, bm, torch, np, scene, cam, accum, W, H, max_bounces, n_super, G, streaming, build_s)
 
     def params(step, flags=0):
         return bm.FrameParams(W, H, spp=spp_step, sample_base=step * spp_step, max_bounces=max_bounces, flags=flags,
@@ -209,6 +216,77 @@ def main():
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_wavefront(args, bm, torch, np, scene, cam, accum, W, H, max_bounces, n_super, G, streaming, build_s):
+    """The reference's queue schedule (bm_wavefront_*): a step is one launch_kernels call = one segment of every path in
+    the 2 Mi-slot queue.  Nominal rays of the metric = paths retired during the timed steps x segments per path."""
+    Q = 2 * 1048576  # ray_queue_buffer_size, variables.h:61
+    segments = max_bounces + 1
+    wf = bm.Wavefront(scene, Q)
+    p = bm.FrameParams(W, H, max_bounces=max_bounces)
+
+    def one_step():
+        wf.frame(cam, p, accum)
+        if streaming:
+            scene.process_load_queue()
+
+    if streaming:
+        for _ in range(64):
+            wf.frame(cam, p, accum)
+            if scene.process_load_queue() == 0:
+                break
+    for _ in range(max(args.warmup, 2 * segments)):  # the bounce mix of the queue reaches its steady state
+        one_step()
+    torch.cuda.synchronize()
+    retired0 = float(accum[..., 3].sum(dtype=torch.float64).item())  # alpha counts terminated paths (kernel.cu:301,322)
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    retired = float(accum[..., 3].sum(dtype=torch.float64).item()) - retired0
+    value = retired * segments / elapsed / 1e6
+    # ---- per-kernel durations and algorithmic bytes of the same steady state (separate, untimed frames)
+    pc = bm.FrameParams(W, H, max_bounces=max_bounces, flags=bm.BM_FLAG_COUNTERS)
+    wf.counters_reset()
+    for _ in range(args.steps):
+        wf.frame(cam, pc, accum)
+    ce, cc = wf.counters("extend"), wf.counters("connect")
+    times = []
+    for _ in range(args.steps):
+        wf.frame(cam, p, accum)
+        times.append(wf.times())
+    ms = {k: float(np.mean([t[k] for t in times])) for k in times[0]}
+    # extend kernel: index words + bricks (SURVEY.md 8d) + its queue traffic: 48 B read (origin, direction, normal) and
+    # 16 B written (normal, distance) per slot
+    ext_bytes = (4 * ce["index_loads"] + 64 * ce["brick_tests"]) / args.steps + Q * (48 + 16)
+    achieved = ext_bytes / (ms["extend"] * 1e-3) / 1e9
+    actual = (ce["extend_rays"] + cc["shadow_rays"]) / args.steps
+    out = {
+        "metric": "Mrays/sec (primary x spp x bounces) at 1080p 4-bounce",
+        "value": round(value, 3), "unit": "Mrays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (SimplexNoise terrain built on the CPU by the product generator; reference RNG streams)",
+        "config": {
+            "workload": f"BASELINE {args.workload} scene and camera, reference wavefront schedule: {W}x{H}, queue of {Q} rays, "
+                        f"one segment of every path in flight per step, {segments} segments/path, {n_super}^3 superchunks, "
+                        + ("brick streaming at steady state" if streaming else "all bricks pre-loaded"),
+            "schedule": "wavefront", "width": W, "height": H, "queue_size": Q, "segments": segments, "world_voxels": G,
+            "sharding": "single GPU (the queue schedule does not shard: replicas only)", "world_build_s": round(build_s, 2),
+        },
+        "rays": {"nominal_per_step": retired * segments / args.steps, "paths_retired_per_step": retired / args.steps,
+                 "actual_per_step": actual, "actual_Mrays_s_frame": round(actual / (ms["total"] * 1e-3) / 1e6, 2)},
+        "frame_ms": {k: round(v, 4) for k, v in ms.items()},
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": None, "kernel": "bm::wf_trace<false, false> (extend)", "kernel_ms_avg": round(ms["extend"], 4),
+            "algorithmic_bytes_per_launch": ext_bytes,
+            "counts_per_launch": {k: v / args.steps for k, v in ce.items()},
+        },
+    }
+    print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(W, H, spp, max_bounces, G, cam):

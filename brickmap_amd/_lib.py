@@ -109,6 +109,8 @@ SIGNATURES = {
     "bm_wavefront_stats": (_i, [_vp, _u32p]),
     "bm_wavefront_read_queue": (_i, [_vp, _i, C.c_uint32, C.c_uint32, _vp]),
     "bm_wavefront_times": (_i, [_vp, C.POINTER(C.c_float)]),
+    "bm_wavefront_counters_read": (_i, [_vp, _i, C.POINTER(bm_counters)]),
+    "bm_wavefront_counters_reset": (_i, [_vp]),
     "bm_debug_sincos": (_i, [_i, _i, _vp, _vp, _vp]),
     "bm_debug_sky": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp]),
 }

@@ -216,6 +216,8 @@ int bm_wavefront_read_queue(bm_wavefront* wf, int which, uint32_t first, uint32_
 	return wf->impl.read_queue(which, first, count, host_out);
 }
 int bm_wavefront_times(bm_wavefront* wf, float* ms5) { BM_NEED_WF(wf); return wf->impl.times(ms5); }
+int bm_wavefront_counters_read(bm_wavefront* wf, int which, bm_counters* out) { BM_NEED_WF(wf); return wf->impl.counters_read(which, out); }
+int bm_wavefront_counters_reset(bm_wavefront* wf) { BM_NEED_WF(wf); return wf->impl.counters_reset(); }
 
 int bm_debug_sincos(int device, int n, const float* x_host, float* sin_host, float* cos_host) {
 	if (n <= 0 || !x_host || !sin_host || !cos_host) { set_error("bad argument"); return BM_EINVAL; }

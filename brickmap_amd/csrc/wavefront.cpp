@@ -8,7 +8,7 @@ namespace bm {
 Wavefront::~Wavefront() {
 	if (hipSetDevice(scene_->device()) != hipSuccess) return;
 	(void)hipDeviceSynchronize();
-	(void)hipFree(d_work_); (void)hipFree(d_next_); (void)hipFree(d_shadow_); (void)hipFree(d_state_); (void)hipFree(d_block_counts_);
+	(void)hipFree(d_work_); (void)hipFree(d_next_); (void)hipFree(d_shadow_); (void)hipFree(d_state_); (void)hipFree(d_block_counts_); (void)hipFree(d_counters_);
 	(void)hipFree(d_frame_constants_);
 	if (h_frame_constants_) (void)hipHostFree(h_frame_constants_);
 	for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
@@ -28,6 +28,8 @@ int Wavefront::init() {
 	BM_HIP(hipMemset(d_next_, 0, static_cast<size_t>(queue_size_) * sizeof(WfRay)));
 	BM_HIP(hipMemset(d_shadow_, 0, static_cast<size_t>(queue_size_) * sizeof(WfShadow)));
 	BM_HIP(hipMemset(d_state_, 0, sizeof(WfState)));
+	BM_HIP(hipMalloc(&d_counters_, 2 * sizeof(DeviceCounters)));
+	BM_HIP(hipMemset(d_counters_, 0, 2 * sizeof(DeviceCounters)));
 	for (auto& e : ev_) BM_HIP(hipEventCreate(&e));
 	for (int c = 0; c < 2; ++c)
 		for (int i = 0; i < 2; ++i) blocks_per_cu_[c][i] = wavefront_blocks_per_cu(c != 0, i != 0);
@@ -51,10 +53,10 @@ int Wavefront::frame(const bm_camera* cam, const bm_frame_params* fp, float* acc
 	const unsigned long long pixels = static_cast<unsigned long long>(fp->width) * static_cast<unsigned long long>(fp->height);
 	if (pixels > 0xFFFFFFFFull) { set_error("frame too large"); return BM_EINVAL; }
 	DeviceScene view;
-	DeviceCounters* counters = nullptr;
-	if (int e = scene_->begin_frame(stream, &view, &counters)) return e;
+	if (int e = scene_->begin_frame(stream, &view, nullptr)) return e;
 	const bool instrumented = (fp->flags & BM_FLAG_COUNTERS) != 0;
-	if (!instrumented) counters = nullptr;
+	DeviceCounters* const counters_extend = instrumented ? d_counters_ : nullptr;
+	DeviceCounters* const counters_connect = instrumented ? d_counters_ + 1 : nullptr;
 	const int slot = static_cast<int>(frame_ % kConstantsRing);
 	h_frame_constants_[slot] = fc;
 	const FrameConstants* fc_dev = d_frame_constants_ + slot;
@@ -67,11 +69,11 @@ int Wavefront::frame(const bm_camera* cam, const bm_frame_params* fp, float* acc
 	BM_HIP(hipEventRecord(ev_[0], stream));
 	launch_wf_primary(d_state_, d_work_, fc_dev, queue_size_, static_cast<uint32_t>(pixels), stream);
 	BM_HIP(hipEventRecord(ev_[1], stream));
-	launch_wf_trace(false, view, fc_dev, d_state_, d_work_, d_shadow_, accum, counters, queue_size_, cus * blocks_per_cu_[0][instrumented ? 1 : 0], stream);
+	launch_wf_trace(false, view, fc_dev, d_state_, d_work_, d_shadow_, accum, counters_extend, queue_size_, cus * blocks_per_cu_[0][instrumented ? 1 : 0], stream);
 	BM_HIP(hipEventRecord(ev_[2], stream));
 	launch_wf_shade(d_work_, d_next_, d_shadow_, accum, d_block_counts_, d_state_, fc_dev, queue_size_, stream);
 	BM_HIP(hipEventRecord(ev_[3], stream));
-	launch_wf_trace(true, view, fc_dev, d_state_, d_work_, d_shadow_, accum, counters, queue_size_, cus * blocks_per_cu_[1][instrumented ? 1 : 0], stream);
+	launch_wf_trace(true, view, fc_dev, d_state_, d_work_, d_shadow_, accum, counters_connect, queue_size_, cus * blocks_per_cu_[1][instrumented ? 1 : 0], stream);
 	BM_HIP(hipEventRecord(ev_[4], stream));
 	BM_HIP(hipGetLastError());
 	timed_ = true;
@@ -98,6 +100,26 @@ int Wavefront::read_queue(int which, uint32_t first, uint32_t count, void* host_
 	BM_HIP(hipDeviceSynchronize());
 	if (which == 0) BM_HIP(hipMemcpy(host_out, d_work_ + first, static_cast<size_t>(count) * sizeof(WfRay), hipMemcpyDeviceToHost));
 	else BM_HIP(hipMemcpy(host_out, d_shadow_ + first, static_cast<size_t>(count) * sizeof(WfShadow), hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int Wavefront::counters_read(int which, bm_counters* out) {
+	if (!out || which < 0 || which > 2) { set_error("bad argument"); return BM_EINVAL; }
+	BM_HIP(hipSetDevice(scene_->device()));
+	BM_HIP(hipDeviceSynchronize());
+	DeviceCounters c[2];
+	BM_HIP(hipMemcpy(c, d_counters_, sizeof c, hipMemcpyDeviceToHost));
+	unsigned long long v[8];
+	for (int k = 0; k < 8; ++k) v[k] = (which != 1 ? c[0].v[k] : 0ull) + (which != 0 ? c[1].v[k] : 0ull);
+	out->index_loads = v[0]; out->brick_tests = v[1]; out->byte_tests = v[2]; out->voxel_steps = v[3];
+	out->extend_rays = v[4]; out->shadow_rays = v[5]; out->requests = v[6]; out->paths = v[7];
+	return 0;
+}
+
+int Wavefront::counters_reset() {
+	BM_HIP(hipSetDevice(scene_->device()));
+	BM_HIP(hipDeviceSynchronize());
+	BM_HIP(hipMemset(d_counters_, 0, 2 * sizeof(DeviceCounters)));
 	return 0;
 }
 

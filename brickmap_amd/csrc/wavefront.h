@@ -18,6 +18,8 @@ public:
 	int stats(uint32_t* out6);
 	int read_queue(int which, uint32_t first, uint32_t count, void* host_out);
 	int times(float* ms5);
+	int counters_read(int which, bm_counters* out); // 0 = extend kernel, 1 = connect kernel, 2 = both
+	int counters_reset();
 
 private:
 	Scene* scene_;
@@ -29,6 +31,7 @@ private:
 	WfShadow* d_shadow_ = nullptr;
 	WfState* d_state_ = nullptr;
 	void* d_block_counts_ = nullptr;
+	DeviceCounters* d_counters_ = nullptr; // [0] extend, [1] connect (BM_FLAG_COUNTERS frames)
 	static constexpr int kConstantsRing = 64;
 	FrameConstants* d_frame_constants_ = nullptr;
 	FrameConstants* h_frame_constants_ = nullptr;

@@ -20,10 +20,11 @@
 namespace bm {
 
 #ifndef BM_WF_GRAB
-#define BM_WF_GRAB 128 // queue slots a wave reserves per atomic
+#define BM_WF_GRAB 64 // queue slots a wave reserves per atomic (32: the ticket atomic becomes the bottleneck; 128: too few
+					  // ranges per wave -- 2 Mi slots over ~6000 resident waves -- and the kernel's tail grows)
 #endif
 #ifndef BM_WF_REFILL
-#define BM_WF_REFILL 16 // idle lanes that trigger a refill
+#define BM_WF_REFILL 32 // idle lanes that trigger a refill (ray loads + ray_setup run for that many lanes at once; 16 and 48 are ~5 % slower)
 #endif
 #ifndef BM_WF_QUORUM_DIV
 #define BM_WF_QUORUM_DIV 4

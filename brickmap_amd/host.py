@@ -336,6 +336,15 @@ class Wavefront:
         check(self._L.bm_wavefront_read_queue(self.handle, kind, first, count, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def counters(self, which="both"):
+        """traversal counters of the BM_FLAG_COUNTERS frames: of the "extend" kernel, the "connect" kernel, or "both" """
+        c = bm_counters()
+        check(self._L.bm_wavefront_counters_read(self.handle, {"extend": 0, "connect": 1, "both": 2}[which], C.byref(c)))
+        return c.as_dict()
+
+    def counters_reset(self):
+        check(self._L.bm_wavefront_counters_reset(self.handle))
+
     def times(self):
         """hipEvent durations (ms) of the last frame."""
         ms = (C.c_float * 5)()
@@ -381,7 +390,7 @@ _statics = _LaunchStatics()
 
 
 def launch_kernels(state: State, blit_buffer, gpuScene: Scene, camera: Camera, spp=1, max_bounces=3, flags=0,
-                   sun_position=None, statics=None):
+                   sun_position=None, statics=None, queues: "Wavefront" = None):
     """launch_kernels (launch.h:6, kernel.cu:366-439) for the per-pixel design.
 
     Differences forced by the redesign (DESIGN.md "Boundary"): no GL surface and no ray queues
@@ -389,6 +398,9 @@ def launch_kernels(state: State, blit_buffer, gpuScene: Scene, camera: Camera, s
     every in-flight path by one bounce.  As in the reference, a change of camera position /
     direction / focal distance / lens radius or of the sun resets the accumulation buffer
     (kernel.cu:387-403).  Returns 0 (the reference always returns cudaSuccess, kernel.cu:438).
+
+    With `queues` (a Wavefront: the reference's ray_buffer_work / ray_buffer_next / shadow_queue_buffer) the call is
+    the reference's own schedule instead: every path in flight advances by one segment, `spp` is ignored.
     """
     st = statics or _statics
     if sun_position is not None and tuple(sun_position) != st.sun_position:
@@ -402,6 +414,16 @@ def launch_kernels(state: State, blit_buffer, gpuScene: Scene, camera: Camera, s
     if reset_buffer:
         blit_buffer.zero_()
         st.sample_base = 0
+    if queues is not None:
+        assert state.shard_count == 1, "the queue schedule does not shard"
+        if reset_buffer and not st.first_time:
+            queues.reset()
+        queues.frame(camera, FrameParams(state.screen_width, state.screen_height, max_bounces=max_bounces, flags=flags,
+                                         sun_position=st.sun_position), blit_buffer)
+        st.frame += 1
+        st.first_time = False
+        st.last = key
+        return 0
     params = FrameParams(state.screen_width, state.screen_height, spp=spp, sample_base=st.sample_base, max_bounces=max_bounces,
                          base_frame=1, flags=flags, band_rows=state.band_rows, shard_rank=state.shard_rank,
                          shard_count=state.shard_count, sun_position=st.sun_position)

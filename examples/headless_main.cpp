@@ -1,7 +1,8 @@
 // examples/headless_main.cpp -- the reference's main loop (src/main.cpp:100-147) without the window:
 // State + Scene + generate(), then per frame launch_kernels -> process_load_queue, finally a PPM of the
 // resolved frame.  Build: see `make -C examples` (g++ on this file, linked against libbrickmap_hip.so).
-//   usage: headless_main [grid_size grid_height width height frames out.ppm]
+//   usage: headless_main [grid_size grid_height width height frames out.ppm [wavefront]]
+// With the last argument the frames are rendered with the reference's own queue schedule (one segment per call).
 #include <cstdint>
 #include <fstream>
 #include <iostream>
@@ -16,6 +17,7 @@ int main(int argc, char** argv) {
 	const size_t width = argc > 3 ? std::atoi(argv[3]) : 1920, height = argc > 4 ? std::atoi(argv[4]) : 1080;
 	const int frames = argc > 5 ? std::atoi(argv[5]) : 64;
 	const char* out = argc > 6 ? argv[6] : "frame.ppm";
+	const bool wavefront = argc > 7;
 
 	State state(width, height);                 // main.cpp:102
 	Scene scene(grid_size, grid_height);        // main.cpp:104
@@ -25,9 +27,17 @@ int main(int argc, char** argv) {
 	camera.vertical_angle = -0.5;
 	camera.update();                            // main.cpp:140
 
-	for (int frame = 0; frame < frames; ++frame) {
-		launch_kernels(state, state.blit_buffer, scene.gpuScene); // main.cpp:142
-		scene.process_load_queue();                                 // main.cpp:144
+	if (wavefront) {
+		Wavefront queues(scene.gpuScene); // state.h:19-21: ray_buffer_work / ray_buffer_next / shadow_queue_buffer
+		for (int frame = 0; frame < frames; ++frame) {
+			launch_kernels(state, state.blit_buffer, scene.gpuScene, queues); // main.cpp:142
+			scene.process_load_queue();                                         // main.cpp:144 (the swap of :146 is inside)
+		}
+	} else {
+		for (int frame = 0; frame < frames; ++frame) {
+			launch_kernels(state, state.blit_buffer, scene.gpuScene); // main.cpp:142
+			scene.process_load_queue();                                 // main.cpp:144
+		}
 	}
 
 	// blit_onto_framebuffer (kernel.cu:348-364) into an offscreen buffer instead of the GL surface

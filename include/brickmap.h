@@ -198,6 +198,9 @@ BM_API int bm_wavefront_stats(bm_wavefront* wf, uint32_t* out6);
 BM_API int bm_wavefront_read_queue(bm_wavefront* wf, int which, uint32_t first, uint32_t count, void* host_out);
 /* hipEvent durations (ms) of the last frame: total, primary_rays + globals, extend, shade, connect */
 BM_API int bm_wavefront_times(bm_wavefront* wf, float* ms5);
+/* traversal counters of the frames run with BM_FLAG_COUNTERS: which = 0 the extend kernel, 1 the connect kernel, 2 both */
+BM_API int bm_wavefront_counters_read(bm_wavefront* wf, int which, bm_counters* out);
+BM_API int bm_wavefront_counters_reset(bm_wavefront* wf);
 
 /* ---- numeric-contract probes used by the parity tests (device side of detmath.h etc.) */
 BM_API int bm_debug_sincos(int device, int n, const float* x_host, float* sin_host, float* cos_host);

@@ -4,7 +4,7 @@
 //   Camera          camera.h:3-24, camera.cpp:48-54          (input handling needs a window: out of scope)
 //   State           state.h:5-34                             (ray queues / GL interop are gone: paths live in registers)
 //   Scene           Scene.h:7-44, Scene.cpp:29-258
-//   launch_kernels  launch.h:6, kernel.cu:366-439
+//   launch_kernels  launch.h:6, kernel.cu:366-439            (fused per-pixel paths; or, with a Wavefront, the reference's queue schedule)
 //   hip(...)        assert_cuda.h:5, assert_cuda.cpp:3-13     (print, then exit(code): the reference's cuda() macro)
 // A maintainer swaps `#include "launch.h"` + the CUDA sources for this header and links libbrickmap_hip.so;
 // see INTEGRATION.md for the exact diff against src/main.cpp.
@@ -98,6 +98,37 @@ private:
 	}
 };
 
+namespace detail {
+inline bm_camera camera_to_c() {
+	bm_camera cam{};
+	cam.position[0] = camera.position.x; cam.position[1] = camera.position.y; cam.position[2] = camera.position.z;
+	cam.direction[0] = camera.direction.x; cam.direction[1] = camera.direction.y; cam.direction[2] = camera.direction.z;
+	cam.up[0] = camera.up.x; cam.up[1] = camera.up.y; cam.up[2] = camera.up.z;
+	cam.focal_distance = camera.focalDistance;
+	cam.lens_radius = camera.lensRadius;
+	return cam;
+}
+inline bm_frame_params frame_params(const State& state, int max_bounces) {
+	bm_frame_params fp{};
+	fp.width = static_cast<int32_t>(state.screen_width);
+	fp.height = static_cast<int32_t>(state.screen_height);
+	fp.spp = 1;
+	fp.max_bounces = max_bounces;
+	fp.base_frame = 1;
+	fp.band_rows = fp.height;
+	fp.shard_rank = 0;
+	fp.shard_count = 1;
+	fp.sun_position[0] = sun_position.x;
+	fp.sun_position[1] = sun_position.y;
+	return fp;
+}
+inline bool camera_changed(const Camera& last) {
+	return last.position.x != camera.position.x || last.position.y != camera.position.y || last.position.z != camera.position.z ||
+		   last.direction.x != camera.direction.x || last.direction.y != camera.direction.y || last.direction.z != camera.direction.z ||
+		   last.focalDistance != camera.focalDistance || last.lensRadius != camera.lensRadius;
+}
+} // namespace detail
+
 // launch_kernels (launch.h:6, kernel.cu:366-439).  The cudaSurfaceObject_t and the three queue pointers of the
 // reference signature are gone (no GL surface; paths live in registers); `spp` complete paths per pixel are
 // traced per call instead of one bounce of every in-flight path.  As in the reference the call blocks until
@@ -106,9 +137,7 @@ inline int launch_kernels(State& state, vec4* blit_buffer, Scene::GPUScene gpuSc
 	static bool first_time = true;
 	static int sample_base = 0;
 	static Camera last;
-	bool reset_buffer = first_time || last.position.x != camera.position.x || last.position.y != camera.position.y ||
-						last.position.z != camera.position.z || last.direction.x != camera.direction.x || last.direction.y != camera.direction.y ||
-						last.direction.z != camera.direction.z || last.focalDistance != camera.focalDistance || last.lensRadius != camera.lensRadius;
+	bool reset_buffer = first_time || detail::camera_changed(last);
 	first_time = false;
 	if (sun_position_changed) {
 		sun_position_changed = false;
@@ -118,29 +147,50 @@ inline int launch_kernels(State& state, vec4* blit_buffer, Scene::GPUScene gpuSc
 		BM_CHECKED(bm_buffer_zero(state.device, blit_buffer, state.screen_width * state.screen_height * sizeof(vec4), nullptr));
 		sample_base = 0;
 	}
-	bm_camera cam{};
-	cam.position[0] = camera.position.x; cam.position[1] = camera.position.y; cam.position[2] = camera.position.z;
-	cam.direction[0] = camera.direction.x; cam.direction[1] = camera.direction.y; cam.direction[2] = camera.direction.z;
-	cam.up[0] = camera.up.x; cam.up[1] = camera.up.y; cam.up[2] = camera.up.z;
-	cam.focal_distance = camera.focalDistance;
-	cam.lens_radius = camera.lensRadius;
-	bm_frame_params fp{};
-	fp.width = static_cast<int32_t>(state.screen_width);
-	fp.height = static_cast<int32_t>(state.screen_height);
+	const bm_camera cam = detail::camera_to_c();
+	bm_frame_params fp = detail::frame_params(state, max_bounces);
 	fp.spp = spp;
 	fp.sample_base = sample_base;
-	fp.max_bounces = max_bounces;
-	fp.base_frame = 1;
-	fp.band_rows = fp.height;
-	fp.shard_rank = 0;
-	fp.shard_count = 1;
-	fp.sun_position[0] = sun_position.x;
-	fp.sun_position[1] = sun_position.y;
 	BM_CHECKED(bm_render_frame(gpuScene.handle, &cam, &fp, reinterpret_cast<float*>(blit_buffer), nullptr, nullptr));
 	BM_CHECKED(bm_synchronize(gpuScene.handle));
 	sample_base += spp;
 	last = camera;
 	return 0; // the reference always returns cudaSuccess (kernel.cu:438)
+}
+
+// The reference's own schedule.  RayQueue* queue / queue2 and ShadowQueue* shadowQueue of the reference signature
+// (state.h:19-21) and the statics / __device__ globals of kernel.cu:106-119,369 live in a Wavefront object; one call
+// advances every path in flight by one segment, exactly like the reference's launch_kernels, and the buffer swap of
+// main.cpp:146 happens inside.  `ray_queue_buffer_size` is variables.h:61.
+struct Wavefront {
+	bm_wavefront* handle = nullptr;
+	explicit Wavefront(Scene::GPUScene gpuScene, uint32_t ray_queue_buffer_size = 2 * 1048576) {
+		BM_CHECKED(bm_wavefront_create(gpuScene.handle, ray_queue_buffer_size, &handle));
+	}
+	~Wavefront() { bm_wavefront_destroy(handle); }
+	Wavefront(const Wavefront&) = delete;
+	Wavefront& operator=(const Wavefront&) = delete;
+};
+
+inline int launch_kernels(State& state, vec4* blit_buffer, Scene::GPUScene gpuScene, Wavefront& queues, int max_bounces = 3) {
+	static Camera last;
+	static bool first_time = true;
+	bool reset_buffer = !first_time && detail::camera_changed(last); // kernel.cu:387
+	first_time = false;
+	if (sun_position_changed) { // kernel.cu:389-395
+		sun_position_changed = false;
+		reset_buffer = true;
+	}
+	if (reset_buffer) { // kernel.cu:397-403
+		BM_CHECKED(bm_buffer_zero(state.device, blit_buffer, state.screen_width * state.screen_height * sizeof(vec4), nullptr));
+		BM_CHECKED(bm_wavefront_reset(queues.handle));
+	}
+	const bm_camera cam = detail::camera_to_c();
+	const bm_frame_params fp = detail::frame_params(state, max_bounces);
+	BM_CHECKED(bm_wavefront_frame(queues.handle, &cam, &fp, reinterpret_cast<float*>(blit_buffer), nullptr));
+	BM_CHECKED(bm_synchronize(gpuScene.handle)); // kernel.cu:431
+	last = camera;
+	return 0;
 }
 
 } // namespace brickmap

@@ -54,7 +54,6 @@ def test_wavefront_frames_match_oracle_mode_a(queue_size, bm, orc, torch_cuda):
     p = bm.FrameParams(W, H, max_bounces=3, flags=bm.BM_FLAG_COUNTERS)
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
     oacc = np.zeros((H, W, 4), np.float32)
-    scene.counters_reset()
     cam = bm.Camera(position=(G / 2, G / 8, 0.8 * G), horizontal_angle=0.8, vertical_angle=-0.5).update()
     ocam = orc.make_camera(cam.position, cam.direction)
     for _ in range(6):
@@ -72,7 +71,9 @@ def test_wavefront_frames_match_oracle_mode_a(queue_size, bm, orc, torch_cuda):
         ost = owf.frame(w, ocam, W, H, oacc)
         compare_frame(wf, owf, wf.stats(), ost)
     assert_radiance(acc.cpu().numpy(), oacc)
-    assert scene.counters() == owf.counters()
+    assert wf.counters() == owf.counters()
+    ce, cc = wf.counters("extend"), wf.counters("connect")
+    assert ce["shadow_rays"] == 0 and cc["extend_rays"] == 0 and ce["extend_rays"] == 11 * queue_size
     t = wf.times()
     assert t["total"] > 0 and t["extend"] > 0
     wf.close(); scene.close()
@@ -93,7 +94,6 @@ def test_wavefront_streaming_matches_oracle(bm, orc, torch_cuda):
     p = bm.FrameParams(W, H, max_bounces=3, flags=bm.BM_FLAG_COUNTERS)
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
     oacc = np.zeros((H, W, 4), np.float32)
-    scene.counters_reset()
     cam = bm.Camera(position=(G / 2, G / 8, 0.8 * G), horizontal_angle=0.8, vertical_angle=-0.5).update()
     ocam = orc.make_camera(cam.position, cam.direction)
     serviced = 0
@@ -103,7 +103,7 @@ def test_wavefront_streaming_matches_oracle(bm, orc, torch_cuda):
         ost = owf.frame(w, ocam, W, H, oacc)  # includes the oracle's process_load_queue
         compare_frame(wf, owf, wf.stats(), ost)
     assert_radiance(acc.cpu().numpy(), oacc)
-    cnt, ocnt = scene.counters(), owf.counters()
+    cnt, ocnt = wf.counters(), owf.counters()
     assert cnt == ocnt and ocnt["requests"] > 0 and ocnt["brick_tests"] > 0
     assert serviced == ocnt["requests"] == scene.info()["resident_bricks"]
     wf.close(); scene.close()
@@ -134,3 +134,48 @@ def test_wavefront_frame1_equals_the_reference_run(bm, torch_cuda):
     a = acc.cpu().numpy()
     assert np.isfinite(a).all() and a[..., 3].min() >= 0
     wf.close(); scene.close()
+
+
+def test_wavefront_and_fused_schedules_estimate_the_same_image(bm, torch_cuda):
+    """launch_kernels(queues=Wavefront) is the reference's schedule, launch_kernels() the fused per-pixel one: different
+    RNG streams, same estimator -- after ~100 paths per pixel the two images agree statistically."""
+    torch = torch_cuda
+    G, W, H = 256, 64, 48
+    scene = bm.Scene(G, G, device=0).generate()
+    scene.preload_all()
+    cam = bm.Camera(position=(G / 2, G / 8, 0.8 * G), horizontal_angle=0.8, vertical_angle=-0.5).update()
+    fused, queued = bm.State(W, H), bm.State(W, H)
+    from brickmap_amd.host import _LaunchStatics
+    s1, s2 = _LaunchStatics(), _LaunchStatics()
+    bm.launch_kernels(fused, fused.blit_buffer, scene, cam, spp=128, statics=s1)
+    wf = bm.Wavefront(scene, W * H)
+    for _ in range(400):
+        assert bm.launch_kernels(queued, queued.blit_buffer, scene, cam, statics=s2, queues=wf) == 0
+    a, b = fused.blit_buffer.cpu().numpy(), queued.blit_buffer.cpu().numpy()
+    assert a[..., 3].min() == 128 and b[..., 3].min() > 60  # terminated paths per pixel
+    ia, ib = a[..., :3] / a[..., 3:], b[..., :3] / b[..., 3:]
+    assert abs(ia.mean() - ib.mean()) < 0.02 * ia.mean()
+    assert np.corrcoef(ia.ravel(), ib.ravel())[0, 1] > 0.95
+    # a camera move resets both the frame buffer and the queues (kernel.cu:387-403)
+    cam2 = bm.Camera(position=(40.0, 200.0, 150.0), horizontal_angle=2.1, vertical_angle=-0.3).update()
+    bm.launch_kernels(queued, queued.blit_buffer, scene, cam2, statics=s2, queues=wf)
+    st = wf.stats()
+    assert st["generated"] == W * H  # the whole queue was refilled with primary rays
+    assert float(queued.blit_buffer[..., 3].sum().item()) == W * H - st["survivors"]
+    wf.close(); scene.close()
+
+
+def test_cpp_headless_example_wavefront_schedule(bm, torch_cuda, tmp_path):
+    """include/brickmap.hpp: launch_kernels(state, blit, gpuScene, queues) in the reference's main loop, streaming."""
+    import subprocess
+    from conftest import ROOT
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
+    out = tmp_path / "frame.ppm"
+    r = subprocess.run([os.path.join(ROOT, "examples", "headless_main"), "256", "256", "160", "96", "48", str(out), "wavefront"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    data = out.read_bytes()
+    head = b"P6\n160 96\n255\n"
+    assert data.startswith(head) and len(data) == len(head) + 160 * 96 * 3
+    px = np.frombuffer(data[len(head):], np.uint8)
+    assert px.max() > 0 and len(np.unique(px)) > 16
