@@ -111,6 +111,7 @@ SIGNATURES = {
     "bm_wavefront_times": (_i, [_vp, C.POINTER(C.c_float)]),
     "bm_wavefront_counters_read": (_i, [_vp, _i, C.POINTER(bm_counters)]),
     "bm_wavefront_counters_reset": (_i, [_vp]),
+    "bm_wavefront_sched_stats_read": (_i, [_vp, _i, C.POINTER(C.c_uint64)]),
     "bm_debug_sincos": (_i, [_i, _i, _vp, _vp, _vp]),
     "bm_debug_sky": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp]),
 }

@@ -217,6 +217,10 @@ int bm_wavefront_read_queue(bm_wavefront* wf, int which, uint32_t first, uint32_
 }
 int bm_wavefront_times(bm_wavefront* wf, float* ms5) { BM_NEED_WF(wf); return wf->impl.times(ms5); }
 int bm_wavefront_counters_read(bm_wavefront* wf, int which, bm_counters* out) { BM_NEED_WF(wf); return wf->impl.counters_read(which, out); }
+int bm_wavefront_sched_stats_read(bm_wavefront* wf, int which, uint64_t* out6) {
+	BM_NEED_WF(wf);
+	return wf->impl.sched_stats_read(which, reinterpret_cast<unsigned long long*>(out6));
+}
 int bm_wavefront_counters_reset(bm_wavefront* wf) { BM_NEED_WF(wf); return wf->impl.counters_reset(); }
 
 int bm_debug_sincos(int device, int n, const float* x_host, float* sin_host, float* cos_host) {

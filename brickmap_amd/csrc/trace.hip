@@ -8,10 +8,9 @@
 // operation (IEEE fp32, no contraction; see DESIGN.md "Numeric contract") so that hits are
 // bit-identical to the CPU oracle.
 //
-// Launch geometry: 256-thread workgroups = 16x16 pixel tiles, each wave an 8x8 pixel block
-// (coherent primary rays).  Workgroup b runs on XCD b%8 (observed dispatch rule), so tile
-// columns are dealt to XCDs in contiguous vertical stripes: every XCD's private 4 MiB L2 then
-// caches one wedge of the view frustum, and every XCD sees the same sky/terrain mix.
+// Launch geometry: persistent 256-thread workgroups (compute units x resident blocks); waves pull 4x4-pixel chunks
+// from interleaved ticket counters and schedule their lanes' work in phases (see trace_paths below).
+// The device functions shared with the queue-based schedule (wavefront.hip) live in traverse.h.
 #include "traverse.h"
 
 namespace bm {

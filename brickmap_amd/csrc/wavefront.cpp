@@ -116,6 +116,16 @@ int Wavefront::counters_read(int which, bm_counters* out) {
 	return 0;
 }
 
+int Wavefront::sched_stats_read(int which, unsigned long long* out6) {
+	if (!out6 || which < 0 || which > 1) { set_error("bad argument"); return BM_EINVAL; }
+	BM_HIP(hipSetDevice(scene_->device()));
+	BM_HIP(hipDeviceSynchronize());
+	DeviceCounters c;
+	BM_HIP(hipMemcpy(&c, d_counters_ + which, sizeof c, hipMemcpyDeviceToHost));
+	for (int k = 0; k < 6; ++k) out6[k] = c.sched[k];
+	return 0;
+}
+
 int Wavefront::counters_reset() {
 	BM_HIP(hipSetDevice(scene_->device()));
 	BM_HIP(hipDeviceSynchronize());

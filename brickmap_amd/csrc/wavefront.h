@@ -20,6 +20,7 @@ public:
 	int times(float* ms5);
 	int counters_read(int which, bm_counters* out); // 0 = extend kernel, 1 = connect kernel, 2 = both
 	int counters_reset();
+	int sched_stats_read(int which, unsigned long long* out6); // A runs, A lanes, B runs, B lanes, refills, rays handed out
 
 private:
 	Scene* scene_;

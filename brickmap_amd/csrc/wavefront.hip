@@ -33,6 +33,7 @@ namespace bm {
 #define BM_WF_STEPS 8
 #endif
 
+
 namespace {
 constexpr float kVeryFar = 1e20f; // kernel.cu:12
 enum : int { WF_DEAD = 4 };
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256) void wf_trace(const DeviceScene sc, const Fram
 	uint32_t cur = 0, end = 0; // the wave's private slot range
 	bool work_left = true;
 	long long rounds_left = (static_cast<long long>(total) + 64) * (2ll * sc.cells + sc.cells_height + 64); // hang guard only
+	uint32_t runsA = 0, lanesA = 0, runsB = 0, lanesB = 0, runsR = 0, lanesR = 0; // wave-uniform scheduler statistics (DBG)
 
 	for (;;) {
 		// ---- retire: write the result of every lane whose ray has ended
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(256) void wf_trace(const DeviceScene sc, const Fram
 			}
 			const uint32_t avail = end - cur;
 			const uint32_t take = static_cast<uint32_t>(nN) < avail ? static_cast<uint32_t>(nN) : avail;
+			if (DBG) { runsR++; lanesR += take; }
 			if (take > 0) {
 				const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(need >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(need), 0u));
 				if (state == ST_NEED && rank < take) {
@@ -171,11 +174,13 @@ __global__ __launch_bounds__(256) void wf_trace(const DeviceScene sc, const Fram
 		const int live = nA + nB;
 		if (nB >= (live + BM_WF_QUORUM_DIV - 1) / BM_WF_QUORUM_DIV || nA == 0) {
 			// ---- phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask walk, streaming request)
+			if (DBG) { runsB++; lanesB += nB; }
 			if (state == ST_CAND) state = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick);
 		} else {
 			// ---- phase A: brick-grid moves
 #pragma unroll 1
 			for (int k = 0; k < BM_WF_STEPS; ++k) {
+				if (DBG) { runsA++; lanesA += __popcll(__ballot(state == ST_OUTER)); }
 				if (state == ST_OUTER) state = outer_step<DBG>(sc, r, tally);
 			}
 		}
@@ -188,6 +193,10 @@ __global__ __launch_bounds__(256) void wf_trace(const DeviceScene sc, const Fram
 			unsigned long long t = v[k];
 			for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
 			if (lane == 0 && t) atomicAdd(&counters->v[k], t);
+		}
+		if (lane == 0) { // scheduler statistics: A runs / lanes, B runs / lanes, refills / rays handed out
+			const unsigned long long st8[8] = {runsA, lanesA, runsB, lanesB, runsR, lanesR, 0ull, 0ull};
+			for (int k = 0; k < 8; ++k) atomicAdd(&counters->sched[k], st8[k]);
 		}
 	}
 }

@@ -345,6 +345,13 @@ class Wavefront:
     def counters_reset(self):
         check(self._L.bm_wavefront_counters_reset(self.handle))
 
+    def sched_stats(self, which="extend"):
+        """wave-scheduler statistics of the BM_FLAG_COUNTERS frames of the "extend" or "connect" kernel"""
+        out = (C.c_uint64 * 6)()
+        check(self._L.bm_wavefront_sched_stats_read(self.handle, {"extend": 0, "connect": 1}[which], out))
+        names = ("step_runs", "step_lanes", "candidate_runs", "candidate_lanes", "refills", "refill_rays")
+        return dict(zip(names, (int(v) for v in out)))
+
     def times(self):
         """hipEvent durations (ms) of the last frame."""
         ms = (C.c_float * 5)()

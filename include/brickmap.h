@@ -201,6 +201,9 @@ BM_API int bm_wavefront_times(bm_wavefront* wf, float* ms5);
 /* traversal counters of the frames run with BM_FLAG_COUNTERS: which = 0 the extend kernel, 1 the connect kernel, 2 both */
 BM_API int bm_wavefront_counters_read(bm_wavefront* wf, int which, bm_counters* out);
 BM_API int bm_wavefront_counters_reset(bm_wavefront* wf);
+/* wave-scheduler statistics of the BM_FLAG_COUNTERS frames for kernel `which` (0 extend, 1 connect): out6 = brick-grid
+ * move rounds and the lanes active in them, candidate rounds and lanes, refills and rays handed out */
+BM_API int bm_wavefront_sched_stats_read(bm_wavefront* wf, int which, uint64_t* out6);
 
 /* ---- numeric-contract probes used by the parity tests (device side of detmath.h etc.) */
 BM_API int bm_debug_sincos(int device, int n, const float* x_host, float* sin_host, float* cos_host);

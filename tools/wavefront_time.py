@@ -45,3 +45,15 @@ for f, (t, st) in enumerate(rows):
 tail = rows[8:]
 tot = sum(t["total"] for t, _ in tail); rays = sum(Q + st["shadow"] for _, st in tail)
 print(f"steady state: {tot/len(tail):.3f} ms/frame, {rays/len(tail)/1e6:.2f} M rays/frame -> {rays/tot/1e3:.0f} Mrays/s actual (per-pixel {rays_pp/ms_pp/1e3:.0f})")
+
+# scheduler statistics of the instrumented kernels over 4 steady-state frames
+wf.counters_reset()
+pc = bm.FrameParams(W, H, max_bounces=3, flags=bm.BM_FLAG_COUNTERS)
+for _ in range(4):
+    wf.frame(cam, pc, acc)
+for which in ("extend", "connect"):
+    s, c = wf.sched_stats(which), wf.counters(which)
+    rays = c["extend_rays"] + c["shadow_rays"]
+    print(f"{which}: {rays/4/1e6:.2f} M rays/frame, cells/ray {c['index_loads']/rays:.1f}, candidates/ray {s['candidate_lanes']/rays:.2f}, "
+          f"A lanes/run {s['step_lanes']/max(s['step_runs'],1):.1f}, B lanes/run {s['candidate_lanes']/max(s['candidate_runs'],1):.1f}, "
+          f"refill rays/run {s['refill_rays']/max(s['refills'],1):.1f}, A runs/ray {s['step_runs']/rays*64:.1f}x64, B runs/ray {s['candidate_runs']/rays*64:.2f}x64")
