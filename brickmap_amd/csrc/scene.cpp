@@ -144,8 +144,8 @@ int Scene::init(int grid_size, int grid_height) {
 		set_error("grid_size and grid_height must be positive multiples of 128 voxels");
 		return BM_EINVAL;
 	}
-	if (world.dims.cells > 1024 || world.dims.cells_height > 1024) { // the traversal packs a brick cell into 3 x 10 bits
-		set_error("worlds larger than 8192 voxels per side are not supported");
+	if (world.dims.cells > 1024 || world.dims.cells_height > 992) { // the traversal packs a brick cell into 11 + 11 + 10 bits (traverse.h)
+		set_error("worlds larger than 8192 x 8192 x 7936 voxels are not supported");
 		return BM_EINVAL;
 	}
 	BM_HIP(hipSetDevice(device_));

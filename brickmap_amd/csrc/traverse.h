@@ -148,8 +148,8 @@ struct RayState {
 	f3 o, d;            // origin (brick units once set up) and direction
 	float tx, ty, tz;   // tmax
 	float dx, dy, dz;   // tdelta = |1/d|
-	int px, py, pz;     // current brick cell
-	int sx, sy, sz;     // step signs
+	uint32_t p;         // current brick cell, packed: (x + 16) | (y + 16) << 11 | (z + 16) << 22 (see pack_cell)
+	int sx, stepy, stepz; // packed-cell increment of a move along x / y / z: sign(d) << 0 / 11 / 22 (sy = stepy >> 11, ...)
 	float tminn;
 	f3 n;               // normal carried in/out of the traversal (voxel.cuh:135 `normal`)
 	int axis;           // axis of the last move, -1 before the first
@@ -162,13 +162,29 @@ struct RayState {
 
 enum : int { ST_NEED = 0, ST_OUTER = 1, ST_CAND = 2, ST_FIN = 3 };
 
+// Packed brick cell.  The three coordinates share one register, biased by one supercell (16) so that the cell just
+// outside the grid on the negative side is representable (15) and a move never borrows across fields: a move is ONE
+// add of a per-axis constant, and "did this move cross a 4-brick block / 16-brick supercell boundary" is a test of
+// the bits that changed.  x, y: 11 bits (grids up to 1024 bricks wide), z: 10 bits (up to 992 high); Scene::init checks.
+constexpr uint32_t kCellBias = 16u;
+constexpr uint32_t kBlockBits = 0x7FCu | (0x7FCu << 11) | (0x3FCu << 22); // coordinate bits >= 2 of each field
+constexpr uint32_t kSuperBits = 0x7F0u | (0x7F0u << 11) | (0x3F0u << 22); // coordinate bits >= 4
+__device__ __forceinline__ uint32_t pack_cell(int x, int y, int z) {
+	return (static_cast<uint32_t>(x) + kCellBias) | ((static_cast<uint32_t>(y) + kCellBias) << 11) | ((static_cast<uint32_t>(z) + kCellBias) << 22);
+}
+__device__ __forceinline__ int cell_x(uint32_t p) { return static_cast<int>(p & 0x7FFu) - 16; }
+__device__ __forceinline__ int cell_y(uint32_t p) { return static_cast<int>((p >> 11) & 0x7FFu) - 16; }
+__device__ __forceinline__ int cell_z(uint32_t p) { return static_cast<int>(p >> 22) - 16; }
+
 __device__ __forceinline__ void load_super(const DeviceScene& sc, RayState& r) {
-	r.sci = (r.px >> 4) + (r.py >> 4) * sc.sg_xy + (r.pz >> 4) * sc.sg_xy2;
+	// supercell coordinates = field >> 4, minus the one-supercell bias
+	const int sx = static_cast<int>((r.p >> 4) & 0x7Fu) - 1, sy = static_cast<int>((r.p >> 15) & 0x7Fu) - 1, sz = static_cast<int>(r.p >> 26) - 1;
+	r.sci = sx + sy * sc.sg_xy + sz * sc.sg_xy2;
 	const uint2 rec = *reinterpret_cast<const uint2*>(sc.super_info + r.sci);
 	r.coarse = static_cast<unsigned long long>(rec.x) | (static_cast<unsigned long long>(rec.y) << 32);
 }
 __device__ __forceinline__ void load_block(const DeviceScene& sc, RayState& r) {
-	const int bi = ((r.px >> 2) & 3) + (((r.py >> 2) & 3) << 2) + (((r.pz >> 2) & 3) << 4);
+	const int bi = static_cast<int>(((r.p >> 2) & 3u) | (((r.p >> 13) & 3u) << 2) | (((r.p >> 24) & 3u) << 4));
 	r.fine = 0ull;
 	if ((r.coarse >> bi) & 1ull) {
 		const uint4 rec = *reinterpret_cast<const uint4*>(sc.block_info + (static_cast<size_t>(r.sci) << 6) + bi);
@@ -176,10 +192,8 @@ __device__ __forceinline__ void load_block(const DeviceScene& sc, RayState& r) {
 		r.block_base = rec.z;
 	}
 }
-__device__ __forceinline__ bool cell_occupied(const RayState& r) {
-	const int ci = (r.px & 3) + ((r.py & 3) << 2) + ((r.pz & 3) << 4);
-	return (r.fine >> ci) & 1ull;
-}
+__device__ __forceinline__ int cell_in_block(uint32_t p) { return static_cast<int>((p & 3u) | (((p >> 11) & 3u) << 2) | (((p >> 22) & 3u) << 4)); }
+__device__ __forceinline__ bool cell_occupied(const RayState& r) { return (r.fine >> cell_in_block(r.p)) & 1ull; }
 
 // voxel.cuh:136-189: clip against the world box, move onto it, set up the Amanatides-Woo state.
 // Returns the lane's next state: ST_OUTER / ST_CAND, or ST_NEED with r.hit = false when the ray misses the box.
@@ -218,20 +232,22 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 	}
 	origin = origin / 8.f;
 	r.o = origin;
-	r.px = static_cast<int>(origin.x); r.py = static_cast<int>(origin.y); r.pz = static_cast<int>(origin.z);
+	const int px = static_cast<int>(origin.x), py = static_cast<int>(origin.y), pz = static_cast<int>(origin.z);
 	const int cells = sc.cells, cells_h = sc.cells_height;
-	if (r.px < 0 || r.px >= cells || r.py < 0 || r.py >= cells || r.pz < 0 || r.pz >= cells_h) return ST_NEED;
-	const float cbx = dir.x > 0.f ? static_cast<float>(r.px + 1) : static_cast<float>(r.px);
-	const float cby = dir.y > 0.f ? static_cast<float>(r.py + 1) : static_cast<float>(r.py);
-	const float cbz = dir.z > 0.f ? static_cast<float>(r.pz + 1) : static_cast<float>(r.pz);
-	r.sx = isign(dir.x); r.sy = isign(dir.y); r.sz = isign(dir.z);
+	if (px < 0 || px >= cells || py < 0 || py >= cells || pz < 0 || pz >= cells_h) return ST_NEED;
+	r.p = pack_cell(px, py, pz);
+	const float cbx = dir.x > 0.f ? static_cast<float>(px + 1) : static_cast<float>(px);
+	const float cby = dir.y > 0.f ? static_cast<float>(py + 1) : static_cast<float>(py);
+	const float cbz = dir.z > 0.f ? static_cast<float>(pz + 1) : static_cast<float>(pz);
+	const int sx = isign(dir.x), sy = isign(dir.y), sz = isign(dir.z);
+	r.sx = sx; r.stepy = sy * (1 << 11); r.stepz = sz * (1 << 22);
 	const float rx = dir.x == 0.0f ? 0.0f : 1.f / dir.x;
 	const float ry = dir.y == 0.0f ? 0.0f : 1.f / dir.y;
 	const float rz = dir.z == 0.0f ? 0.0f : 1.f / dir.z;
 	r.tx = dir.x != 0.f ? (cbx - origin.x) * rx : 1000000.f;
 	r.ty = dir.y != 0.f ? (cby - origin.y) * ry : 1000000.f;
 	r.tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
-	r.dx = static_cast<float>(r.sx) * rx; r.dy = static_cast<float>(r.sy) * ry; r.dz = static_cast<float>(r.sz) * rz;
+	r.dx = static_cast<float>(sx) * rx; r.dy = static_cast<float>(sy) * ry; r.dz = static_cast<float>(sz) * rz;
 	r.axis = -1;
 	load_super(sc, r);
 	load_block(sc, r);
@@ -246,27 +262,27 @@ template <bool DBG>
 __device__ __forceinline__ int outer_step(const DeviceScene& sc, RayState& r, Tally& tally) {
 	// work on scalar copies: selects between struct members would otherwise pin the struct in scratch memory
 	const float tx = r.tx, ty = r.ty, tz = r.tz;
-	const int sx = r.sx, sy = r.sy, sz = r.sz;
 	const bool mx = tx < ty && tx < tz;
 	const bool my = ty <= tx && ty < tz; // mx implies !my
 	const bool mz = !(mx || my);
-	const int npx = r.px + (mx ? sx : 0);
-	const int npy = r.py + (my ? sy : 0);
-	const int npz = r.pz + (mz ? sz : 0);
-	r.px = npx; r.py = npy; r.pz = npz;
+	const uint32_t old = r.p;
+	const int step_x = r.sx, step_y = r.stepy, step_z = r.stepz;
+	const uint32_t np = old + static_cast<uint32_t>(mx ? step_x : (my ? step_y : step_z)); // pos += mask * step
+	r.p = np;
 	r.tx = tx + (mx ? r.dx : 0.f);
 	r.ty = ty + (my ? r.dy : 0.f);
 	r.tz = tz + (mz ? r.dz : 0.f);
 	r.axis = mx ? 0 : (my ? 1 : 2);
-	const int s_sel = mx ? sx : (my ? sy : sz);
-	const int c = mx ? npx : (my ? npy : npz);
-	// a move along -axis crosses a 4- / 16-aligned boundary when the NEW coordinate + 1 is aligned
-	const int ce = c - (s_sel >> 31);
-	if ((ce & 3) == 0) {
-		if ((ce & 15) == 0) {
-			// supercell boundary; the world edge is one of them, so the exit test (voxel.cuh:256) lives here
-			const int lim = mz ? sc.cells_height : sc.cells;
-			if (c == (s_sel > 0 ? lim : -1)) return ST_NEED; // left the grid: miss (r.hit stays false)
+	const uint32_t changed = old ^ np;
+	if (changed & kBlockBits) { // the move crossed a 4-aligned boundary
+		if (changed & kSuperBits) {
+			// supercell boundary; the world edge is one of them, so the exit test (voxel.cuh:256) lives here: only the
+			// coordinate that moved can have left its range
+			// (unsigned compares: -1 wraps to a huge value; combined without short-circuit branches)
+			const uint32_t ux = static_cast<uint32_t>(cell_x(np)), uy = static_cast<uint32_t>(cell_y(np)), uz = static_cast<uint32_t>(cell_z(np));
+			const uint32_t uxy = ux > uy ? ux : uy;
+			const int outside = static_cast<int>(uxy >= static_cast<uint32_t>(sc.cells)) | static_cast<int>(uz >= static_cast<uint32_t>(sc.cells_height));
+			if (outside) return ST_NEED; // left the grid: miss (r.hit stays false)
 			load_super(sc, r);
 		}
 		load_block(sc, r);
@@ -279,13 +295,14 @@ __device__ __forceinline__ int outer_step(const DeviceScene& sc, RayState& r, Ta
 template <bool DBG>
 __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const int* campos, RayState& r, HitInfo& info, Tally& tally,
 													 unsigned long long* lds_brick) {
-	const int px = r.px, py = r.py, pz = r.pz;
+	const int px = cell_x(r.p), py = cell_y(r.p), pz = cell_z(r.p);
+	const int sx = r.sx, sy = r.stepy >> 11, sz = r.stepz >> 22; // step signs back from the packed increments
 	// inside the grid 0 <= pos < cells, so >>4 and &15 equal the reference's signed /16 and %16
 	const uint32_t flat = (static_cast<uint32_t>(r.sci) << 12) + static_cast<uint32_t>((px & 15) + ((py & 15) << 4) + ((pz & 15) << 8));
 	// Home slot of this brick: block base + rank of its bit in the block mask.  It does not depend on the index
 	// word, so the 64-byte brick read is issued together with the index-word read instead of behind it (every
 	// non-empty cell owns its slot whether or not the brick is resident, so the read is always in bounds).
-	const int ci = (px & 3) + ((py & 3) << 2) + ((pz & 3) << 4);
+	const int ci = cell_in_block(r.p);
 	const uint32_t slot = r.block_base + static_cast<uint32_t>(__popcll(r.fine & ((1ull << ci) - 1ull)));
 	const uint4* bq = reinterpret_cast<const uint4*>(sc.brick_arena + (static_cast<size_t>(slot) << 4));
 	const uint32_t index = sc.index_grid[flat];
@@ -294,9 +311,9 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	float new_distance = 0.f;
 	if (r.axis != -1) {
 		r.n = mk(0.f, 0.f, 0.f);
-		if (r.axis == 0) { r.n.x = -static_cast<float>(r.sx); new_distance = r.tx - r.dx; }
-		else if (r.axis == 1) { r.n.y = -static_cast<float>(r.sy); new_distance = r.ty - r.dy; }
-		else { r.n.z = -static_cast<float>(r.sz); new_distance = r.tz - r.dz; }
+		if (r.axis == 0) { r.n.x = -static_cast<float>(sx); new_distance = r.tx - r.dx; }
+		else if (r.axis == 1) { r.n.y = -static_cast<float>(sy); new_distance = r.ty - r.dy; }
+		else { r.n.z = -static_cast<float>(sz); new_distance = r.tz - r.dz; }
 	}
 	const int ddx = campos[0] - px, ddy = campos[1] - py, ddz = campos[2] - pz;
 	const int lod2 = ddx * ddx + ddy * ddy + ddz * ddz;
@@ -311,7 +328,7 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 		if (DBG) tally.byte_tests++;
 		int sub = 0;
 		const f3 o2 = (r.o + r.d * new_distance) * 2.f - r.n * 0.2f * kEpsilon;
-		if (intersect_grid<2, DBG>(o2, r.d, r.sx, r.sy, r.sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, (index & kLodBits) >> 12, sub, tally)) {
+		if (intersect_grid<2, DBG>(o2, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, (index & kLodBits) >> 12, sub, tally)) {
 			r.distance = new_distance * 8.f + sub_distance * 4.f + r.tminn;
 			if (DBG) { info.level = 1; info.sub_id = sub; }
 			r.hit = true;
@@ -321,7 +338,7 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 		if (DBG) tally.brick_tests++;
 		int sub = 0;
 		const f3 o8 = (r.o + r.d * new_distance) * 8.f - r.n * kEpsilon;
-		if (intersect_grid<8, DBG>(o8, r.d, r.sx, r.sy, r.sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick)) {
+		if (intersect_grid<8, DBG>(o8, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick)) {
 			r.distance = new_distance * 8.f + sub_distance + r.tminn;
 			if (DBG) { info.level = 2; info.sub_id = sub; }
 			r.hit = true;

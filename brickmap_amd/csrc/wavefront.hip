@@ -80,7 +80,7 @@ __global__ void wf_globals(WfState* st, uint32_t queue_size, uint32_t pixels) {
 // extend (kernel.cu:226-238) when !CONNECT: intersect every ray of the work queue, write distance + normal back.
 // connect (kernel.cu:328-346) when CONNECT: intersect every shadow ray, add its colour to the pixel if unoccluded.
 template <bool CONNECT, bool DBG>
-__global__ __launch_bounds__(256) void wf_trace(const DeviceScene sc, const FrameConstants* __restrict__ fcp, WfState* __restrict__ st,
+__global__ __launch_bounds__(256, DBG ? 4 : 6) void wf_trace(const DeviceScene sc, const FrameConstants* __restrict__ fcp, WfState* __restrict__ st,
 											   WfRay* __restrict__ work, const WfShadow* __restrict__ shadow, float4* __restrict__ accum,
 											   DeviceCounters* __restrict__ counters, uint32_t queue_size) {
 	const FrameConstants& fc = *fcp;
