@@ -15,14 +15,19 @@ namespace bm {
 //                                         block (bx,by,bz) of the supercell holds any non-empty brick;
 //                                         brick_base = first arena slot of the supercell (exclusive
 //                                         prefix sum of non-empty brick counts; replaces Brick**)
-//   block_info  16 B per 4x4x4-brick block {u64 mask, u32 base, u32 0}: mask bit (cx + 4*cy + 16*cz) = "index
-//                                         word of that brick is non-zero".  Static (residency flags never
+//   block_grid  16 B per 4x4x4-brick block {u64 mask, u32 base, u32 outside}, a dense x-fastest 3-D array over the
+//                                         whole grid plus a one-block border: mask bit (cx + 4*cy + 16*cz) =
+//                                         "index word of that brick is non-zero".  Static (residency flags never
 //                                         make a word zero), so the DDA can skip the index load of empty
 //                                         cells while still performing the reference's per-cell arithmetic.
 //                                         base = arena slot of the block's first brick: bricks are stored
 //                                         block by block in mask-bit order, so a brick's slot is
 //                                         base + popcount(mask below its bit) -- known before (and fetched
-//                                         in parallel with) its index word.
+//                                         in parallel with) its index word.  Border blocks have outside = 1:
+//                                         a ray that steps off the grid reads one, which IS the reference's
+//                                         per-step exit test (voxel.cuh:256) -- the walk needs no bounds
+//                                         compare, no supercell bookkeeping and one independent 16-byte load
+//                                         per block boundary crossed.
 //   brick_arena 64 B * total_bricks      exact-fit pool, every brick has a fixed home slot; the 12-bit slot of
 //                                         a device index word is that slot relative to brick_base
 //   load_queue  int3[queue_cap] + count  brick-request ring (voxel.cuh:228-245)
@@ -43,7 +48,8 @@ static_assert(sizeof(BlockInfo) == 16, "one dwordx4 per block");
 struct DeviceScene {
 	uint32_t* index_grid;
 	const SuperInfo* super_info;
-	const BlockInfo* block_info;
+	const BlockInfo* block_grid; // dense, bordered (see above)
+	int bg_x, bg_xy, bg_bias;    // row / slice pitch in blocks; bias = 3 * (1 + bg_x + bg_xy): see load_block
 	const uint32_t* brick_arena; // 16 words per brick
 	int* load_queue;             // 3 ints per entry
 	uint32_t* load_queue_count;

@@ -246,11 +246,11 @@ int Scene::set_queue_capacity(int cap) {
 void Scene::free_device() {
 	if (d_index_grid_) hipFree(d_index_grid_);
 	if (d_super_info_) hipFree(d_super_info_);
-	if (d_block_info_) hipFree(d_block_info_);
+	if (d_block_grid_) hipFree(d_block_grid_);
 	if (d_arena_) hipFree(d_arena_);
 	d_index_grid_ = d_arena_ = nullptr;
 	d_super_info_ = nullptr;
-	d_block_info_ = nullptr;
+	d_block_grid_ = nullptr;
 	on_device_ = false;
 }
 
@@ -271,22 +271,32 @@ int Scene::allocate_device() {
 	const size_t index_bytes = static_cast<size_t>(d.supercells) * kCellsPerSupercell * sizeof(uint32_t);
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_index_grid_), index_bytes));
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_super_info_), static_cast<size_t>(d.supercells) * sizeof(SuperInfo)));
-	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_block_info_), static_cast<size_t>(d.supercells) * 64 * sizeof(BlockInfo)));
+	// dense block grid with a one-block border of "outside" records (device_types.h)
+	const int nbx = d.cells / 4 + 2, nbz = d.cells_height / 4 + 2;
+	const size_t n_blocks = static_cast<size_t>(nbx) * nbx * nbz;
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_block_grid_), n_blocks * sizeof(BlockInfo)));
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_arena_), std::max<size_t>(64, static_cast<size_t>(total_bricks_) * sizeof(Brick))));
 	{
 		std::vector<SuperInfo> info(d.supercells);
-		std::vector<BlockInfo> blocks(static_cast<size_t>(d.supercells) * 64);
+		std::vector<BlockInfo> blocks(n_blocks, BlockInfo{0ull, 0u, 1u}); // border: outside
 		for (int i = 0; i < d.supercells; ++i) {
 			const HostSupercell& c = world.supercells[i];
 			info[i] = SuperInfo{c.coarse_mask, brick_base_[i], 0u};
-			for (int b = 0; b < 64; ++b) blocks[static_cast<size_t>(i) * 64 + b] = BlockInfo{c.fine_mask[b], brick_base_[i] + c.block_base[b], 0u};
+			const int sx = i % d.supergrid_xy, sy = (i / d.supergrid_xy) % d.supergrid_xy, sz = i / (d.supergrid_xy * d.supergrid_xy);
+			for (int b = 0; b < 64; ++b) {
+				const int bx = sx * 4 + (b & 3), by = sy * 4 + ((b >> 2) & 3), bz = sz * 4 + (b >> 4);
+				blocks[(static_cast<size_t>(bz + 1) * nbx + (by + 1)) * nbx + (bx + 1)] = BlockInfo{c.fine_mask[b], brick_base_[i] + c.block_base[b], 0u};
+			}
 		}
 		BM_HIP(hipMemcpy(d_super_info_, info.data(), info.size() * sizeof(SuperInfo), hipMemcpyHostToDevice));
-		BM_HIP(hipMemcpy(d_block_info_, blocks.data(), blocks.size() * sizeof(BlockInfo), hipMemcpyHostToDevice));
+		BM_HIP(hipMemcpy(d_block_grid_, blocks.data(), blocks.size() * sizeof(BlockInfo), hipMemcpyHostToDevice));
 	}
 	view_.index_grid = d_index_grid_;
 	view_.super_info = d_super_info_;
-	view_.block_info = d_block_info_;
+	view_.block_grid = d_block_grid_;
+	view_.bg_x = nbx;
+	view_.bg_xy = nbx * nbx;
+	view_.bg_bias = 3 * (1 + nbx + nbx * nbx);
 	view_.brick_arena = d_arena_;
 	view_.cells = d.cells;
 	view_.cells_height = d.cells_height;

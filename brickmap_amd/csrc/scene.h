@@ -83,7 +83,7 @@ private:
 	// device memory (DeviceScene view)
 	uint32_t* d_index_grid_ = nullptr;
 	SuperInfo* d_super_info_ = nullptr;
-	BlockInfo* d_block_info_ = nullptr;
+	BlockInfo* d_block_grid_ = nullptr;
 	uint32_t* d_arena_ = nullptr;
 	// two request rings: the blocking (reference-order) mode only uses ring 0; the overlapped mode alternates them so
 	// that a frame can raise requests while the previous frame's ring is being copied out and serviced

@@ -153,9 +153,8 @@ struct RayState {
 	float tminn;
 	f3 n;               // normal carried in/out of the traversal (voxel.cuh:135 `normal`)
 	int axis;           // axis of the last move, -1 before the first
-	unsigned long long coarse, fine;
-	uint32_t block_base; // arena slot of the current block's first brick
-	int sci;
+	unsigned long long fine; // occupancy mask of the current 4x4x4-brick block
+	uint32_t block_base;     // arena slot of the current block's first brick
 	float distance;     // result
 	bool hit;
 };
@@ -168,7 +167,6 @@ enum : int { ST_NEED = 0, ST_OUTER = 1, ST_CAND = 2, ST_FIN = 3 };
 // the bits that changed.  x, y: 11 bits (grids up to 1024 bricks wide), z: 10 bits (up to 992 high); Scene::init checks.
 constexpr uint32_t kCellBias = 16u;
 constexpr uint32_t kBlockBits = 0x7FCu | (0x7FCu << 11) | (0x3FCu << 22); // coordinate bits >= 2 of each field
-constexpr uint32_t kSuperBits = 0x7F0u | (0x7F0u << 11) | (0x3F0u << 22); // coordinate bits >= 4
 __device__ __forceinline__ uint32_t pack_cell(int x, int y, int z) {
 	return (static_cast<uint32_t>(x) + kCellBias) | ((static_cast<uint32_t>(y) + kCellBias) << 11) | ((static_cast<uint32_t>(z) + kCellBias) << 22);
 }
@@ -176,21 +174,16 @@ __device__ __forceinline__ int cell_x(uint32_t p) { return static_cast<int>(p & 
 __device__ __forceinline__ int cell_y(uint32_t p) { return static_cast<int>((p >> 11) & 0x7FFu) - 16; }
 __device__ __forceinline__ int cell_z(uint32_t p) { return static_cast<int>(p >> 22) - 16; }
 
-__device__ __forceinline__ void load_super(const DeviceScene& sc, RayState& r) {
-	// supercell coordinates = field >> 4, minus the one-supercell bias
-	const int sx = static_cast<int>((r.p >> 4) & 0x7Fu) - 1, sy = static_cast<int>((r.p >> 15) & 0x7Fu) - 1, sz = static_cast<int>(r.p >> 26) - 1;
-	r.sci = sx + sy * sc.sg_xy + sz * sc.sg_xy2;
-	const uint2 rec = *reinterpret_cast<const uint2*>(sc.super_info + r.sci);
-	r.coarse = static_cast<unsigned long long>(rec.x) | (static_cast<unsigned long long>(rec.y) << 32);
-}
-__device__ __forceinline__ void load_block(const DeviceScene& sc, RayState& r) {
-	const int bi = static_cast<int>(((r.p >> 2) & 3u) | (((r.p >> 13) & 3u) << 2) | (((r.p >> 24) & 3u) << 4));
-	r.fine = 0ull;
-	if ((r.coarse >> bi) & 1ull) {
-		const uint4 rec = *reinterpret_cast<const uint4*>(sc.block_info + (static_cast<size_t>(r.sci) << 6) + bi);
-		r.fine = static_cast<unsigned long long>(rec.x) | (static_cast<unsigned long long>(rec.y) << 32);
-		r.block_base = rec.z;
-	}
+// Read the record of the block the ray is in (dense bordered grid, device_types.h).  Block coordinate + 1 (border)
+// = (field >> 2) - 3 because of the 16-cell bias; the three "- 3" are folded into sc.bg_bias.
+// Returns false when the block is a border block: the ray has left the grid.
+__device__ __forceinline__ bool load_block(const DeviceScene& sc, RayState& r) {
+	const int bx = static_cast<int>((r.p >> 2) & 0x1FFu), by = static_cast<int>((r.p >> 13) & 0x1FFu), bz = static_cast<int>(r.p >> 24);
+	const int idx = bx + by * sc.bg_x + bz * sc.bg_xy - sc.bg_bias;
+	const uint4 rec = *reinterpret_cast<const uint4*>(sc.block_grid + idx);
+	r.fine = static_cast<unsigned long long>(rec.x) | (static_cast<unsigned long long>(rec.y) << 32);
+	r.block_base = rec.z;
+	return rec.w == 0u;
 }
 __device__ __forceinline__ int cell_in_block(uint32_t p) { return static_cast<int>((p & 3u) | (((p >> 11) & 3u) << 2) | (((p >> 22) & 3u) << 4)); }
 __device__ __forceinline__ bool cell_occupied(const RayState& r) { return (r.fine >> cell_in_block(r.p)) & 1ull; }
@@ -249,8 +242,7 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 	r.tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
 	r.dx = static_cast<float>(sx) * rx; r.dy = static_cast<float>(sy) * ry; r.dz = static_cast<float>(sz) * rz;
 	r.axis = -1;
-	load_super(sc, r);
-	load_block(sc, r);
+	load_block(sc, r); // inside the grid: never a border block
 	if (DBG) tally.index_loads++; // one per visited cell = the reference's index loads (algorithmic count)
 	return cell_occupied(r) ? ST_CAND : ST_OUTER;
 }
@@ -274,18 +266,8 @@ __device__ __forceinline__ int outer_step(const DeviceScene& sc, RayState& r, Ta
 	r.tz = tz + (mz ? r.dz : 0.f);
 	r.axis = mx ? 0 : (my ? 1 : 2);
 	const uint32_t changed = old ^ np;
-	if (changed & kBlockBits) { // the move crossed a 4-aligned boundary
-		if (changed & kSuperBits) {
-			// supercell boundary; the world edge is one of them, so the exit test (voxel.cuh:256) lives here: only the
-			// coordinate that moved can have left its range
-			// (unsigned compares: -1 wraps to a huge value; combined without short-circuit branches)
-			const uint32_t ux = static_cast<uint32_t>(cell_x(np)), uy = static_cast<uint32_t>(cell_y(np)), uz = static_cast<uint32_t>(cell_z(np));
-			const uint32_t uxy = ux > uy ? ux : uy;
-			const int outside = static_cast<int>(uxy >= static_cast<uint32_t>(sc.cells)) | static_cast<int>(uz >= static_cast<uint32_t>(sc.cells_height));
-			if (outside) return ST_NEED; // left the grid: miss (r.hit stays false)
-			load_super(sc, r);
-		}
-		load_block(sc, r);
+	if (changed & kBlockBits) { // the move crossed a 4-aligned boundary (the world edge is one: exit test, voxel.cuh:256)
+		if (!load_block(sc, r)) return ST_NEED; // left the grid: miss (r.hit stays false)
 	}
 	if (DBG) tally.index_loads++;
 	return cell_occupied(r) ? ST_CAND : ST_OUTER;
@@ -298,7 +280,8 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	const int px = cell_x(r.p), py = cell_y(r.p), pz = cell_z(r.p);
 	const int sx = r.sx, sy = r.stepy >> 11, sz = r.stepz >> 22; // step signs back from the packed increments
 	// inside the grid 0 <= pos < cells, so >>4 and &15 equal the reference's signed /16 and %16
-	const uint32_t flat = (static_cast<uint32_t>(r.sci) << 12) + static_cast<uint32_t>((px & 15) + ((py & 15) << 4) + ((pz & 15) << 8));
+	const uint32_t sci = static_cast<uint32_t>((px >> 4) + (py >> 4) * sc.sg_xy + (pz >> 4) * sc.sg_xy2);
+	const uint32_t flat = (sci << 12) + static_cast<uint32_t>((px & 15) + ((py & 15) << 4) + ((pz & 15) << 8));
 	// Home slot of this brick: block base + rank of its bit in the block mask.  It does not depend on the index
 	// word, so the 64-byte brick read is issued together with the index-word read instead of behind it (every
 	// non-empty cell owns its slot whether or not the brick is resident, so the read is always in bounds).

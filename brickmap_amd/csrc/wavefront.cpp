@@ -1,6 +1,8 @@
 // wavefront.cpp -- see wavefront.h
 #include "wavefront.h"
 
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace bm {
@@ -33,6 +35,12 @@ int Wavefront::init() {
 	for (auto& e : ev_) BM_HIP(hipEventCreate(&e));
 	for (int c = 0; c < 2; ++c)
 		for (int i = 0; i < 2; ++i) blocks_per_cu_[c][i] = wavefront_blocks_per_cu(c != 0, i != 0);
+	if (const char* cap = std::getenv("BM_WF_BLOCKS_PER_CU")) { // experiment knob: fewer resident waves per SIMD
+		const int n = std::atoi(cap);
+		for (int c = 0; c < 2; ++c)
+			for (int i = 0; i < 2; ++i)
+				if (n > 0 && n < blocks_per_cu_[c][i]) blocks_per_cu_[c][i] = n;
+	}
 	return 0;
 }
 
