@@ -49,7 +49,7 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #define BM_QUORUM_CONN_DIV 8
 #endif
 #ifndef BM_STEPS_PER_ROUND
-#define BM_STEPS_PER_ROUND 8
+#define BM_STEPS_PER_ROUND 12
 #endif
 // -DBM_PHASE_TIMING: profiling build in which the plain kernel also reports the scheduler statistics
 #ifdef BM_PHASE_TIMING

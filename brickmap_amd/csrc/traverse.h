@@ -178,8 +178,9 @@ __device__ __forceinline__ int cell_z(uint32_t p) { return static_cast<int>(p >>
 // = (field >> 2) - 3 because of the 16-cell bias; the three "- 3" are folded into sc.bg_bias.
 // Returns false when the block is a border block: the ray has left the grid.
 __device__ __forceinline__ bool load_block(const DeviceScene& sc, RayState& r) {
-	const int bx = static_cast<int>((r.p >> 2) & 0x1FFu), by = static_cast<int>((r.p >> 13) & 0x1FFu), bz = static_cast<int>(r.p >> 24);
-	const int idx = bx + by * sc.bg_x + bz * sc.bg_xy - sc.bg_bias;
+	const uint32_t bx = (r.p >> 2) & 0x1FFu, by = (r.p >> 13) & 0x1FFu, bz = r.p >> 24;
+	// 24-bit multiply-adds (full rate; a 32-bit v_mul_lo_u32 issues at a quarter of it): all operands are < 2^24
+	const uint32_t idx = __umul24(bz, static_cast<uint32_t>(sc.bg_xy)) + (__umul24(by, static_cast<uint32_t>(sc.bg_x)) + (bx - static_cast<uint32_t>(sc.bg_bias)));
 	const uint4 rec = *reinterpret_cast<const uint4*>(sc.block_grid + idx);
 	r.fine = static_cast<unsigned long long>(rec.x) | (static_cast<unsigned long long>(rec.y) << 32);
 	r.block_base = rec.z;
