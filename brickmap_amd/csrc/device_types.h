@@ -48,8 +48,9 @@ static_assert(sizeof(BlockInfo) == 16, "one dwordx4 per block");
 struct DeviceScene {
 	uint32_t* index_grid;
 	const SuperInfo* super_info;
-	const BlockInfo* block_grid; // dense, bordered (see above)
-	int bg_x, bg_xy, bg_bias;    // row / slice pitch in blocks; bias = 3 * (1 + bg_x + bg_xy): see load_block
+	const BlockInfo* block_grid; // dense, bordered (see above); points 3 * (1 + bg_x + bg_xy) records BEFORE the array: the
+	                             // walk indexes it with block coordinates that carry the packed cell's bias (load_block)
+	int bg_x, bg_xy;             // row / slice pitch in blocks
 	const uint32_t* brick_arena; // 16 words per brick
 	int* load_queue;             // 3 ints per entry
 	uint32_t* load_queue_count;

@@ -293,10 +293,10 @@ int Scene::allocate_device() {
 	}
 	view_.index_grid = d_index_grid_;
 	view_.super_info = d_super_info_;
-	view_.block_grid = d_block_grid_;
+	view_.block_grid = reinterpret_cast<const BlockInfo*>(reinterpret_cast<uintptr_t>(d_block_grid_) -
+														   static_cast<uintptr_t>(3) * (1 + nbx + nbx * nbx) * sizeof(BlockInfo));
 	view_.bg_x = nbx;
 	view_.bg_xy = nbx * nbx;
-	view_.bg_bias = 3 * (1 + nbx + nbx * nbx);
 	view_.brick_arena = d_arena_;
 	view_.cells = d.cells;
 	view_.cells_height = d.cells_height;

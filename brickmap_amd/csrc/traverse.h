@@ -152,7 +152,7 @@ struct RayState {
 	int sx, stepy, stepz; // packed-cell increment of a move along x / y / z: sign(d) << 0 / 11 / 22 (sy = stepy >> 11, ...)
 	float tminn;
 	f3 n;               // normal carried in/out of the traversal (voxel.cuh:135 `normal`)
-	int axis;           // axis of the last move, -1 before the first
+	int last_step;      // packed-cell increment of the last move (0 before the first): which axis it was, see move_axis
 	unsigned long long fine; // occupancy mask of the current 4x4x4-brick block
 	uint32_t block_base;     // arena slot of the current block's first brick
 	float distance;     // result
@@ -166,7 +166,6 @@ enum : int { ST_NEED = 0, ST_OUTER = 1, ST_CAND = 2, ST_FIN = 3 };
 // add of a per-axis constant, and "did this move cross a 4-brick block / 16-brick supercell boundary" is a test of
 // the bits that changed.  x, y: 11 bits (grids up to 1024 bricks wide), z: 10 bits (up to 992 high); Scene::init checks.
 constexpr uint32_t kCellBias = 16u;
-constexpr uint32_t kBlockBits = 0x7FCu | (0x7FCu << 11) | (0x3FCu << 22); // coordinate bits >= 2 of each field
 __device__ __forceinline__ uint32_t pack_cell(int x, int y, int z) {
 	return (static_cast<uint32_t>(x) + kCellBias) | ((static_cast<uint32_t>(y) + kCellBias) << 11) | ((static_cast<uint32_t>(z) + kCellBias) << 22);
 }
@@ -175,19 +174,29 @@ __device__ __forceinline__ int cell_y(uint32_t p) { return static_cast<int>((p >
 __device__ __forceinline__ int cell_z(uint32_t p) { return static_cast<int>(p >> 22) - 16; }
 
 // Read the record of the block the ray is in (dense bordered grid, device_types.h).  Block coordinate + 1 (border)
-// = (field >> 2) - 3 because of the 16-cell bias; the three "- 3" are folded into sc.bg_bias.
+// = (field >> 2) - 3 because of the 16-cell bias; the three "- 3" are folded into the base pointer sc.block_grid.
 // Returns false when the block is a border block: the ray has left the grid.
 __device__ __forceinline__ bool load_block(const DeviceScene& sc, RayState& r) {
 	const uint32_t bx = (r.p >> 2) & 0x1FFu, by = (r.p >> 13) & 0x1FFu, bz = r.p >> 24;
 	// 24-bit multiply-adds (full rate; a 32-bit v_mul_lo_u32 issues at a quarter of it): all operands are < 2^24
-	const uint32_t idx = __umul24(bz, static_cast<uint32_t>(sc.bg_xy)) + (__umul24(by, static_cast<uint32_t>(sc.bg_x)) + (bx - static_cast<uint32_t>(sc.bg_bias)));
+	const uint32_t idx = __umul24(bz, static_cast<uint32_t>(sc.bg_xy)) + (__umul24(by, static_cast<uint32_t>(sc.bg_x)) + bx);
 	const uint4 rec = *reinterpret_cast<const uint4*>(sc.block_grid + idx);
 	r.fine = static_cast<unsigned long long>(rec.x) | (static_cast<unsigned long long>(rec.y) << 32);
 	r.block_base = rec.z;
 	return rec.w == 0u;
 }
-__device__ __forceinline__ int cell_in_block(uint32_t p) { return static_cast<int>((p & 3u) | (((p >> 11) & 3u) << 2) | (((p >> 22) & 3u) << 4)); }
-__device__ __forceinline__ bool cell_occupied(const RayState& r) { return (r.fine >> cell_in_block(r.p)) & 1ull; }
+// Cell index inside its block, (x & 3) | (y & 3) << 2 | (z & 3) << 4.  The three 2-bit groups sit at bits 0, 11 and 22 of
+// the packed cell; one 24-bit multiply by 2^18 + 2^9 + 1 lines them up at bits 18..23 (no two partial products overlap).
+__device__ __forceinline__ uint32_t cell_in_block_shifted(uint32_t p) { return __umul24(p & 0x00C01803u, (1u << 18) | (1u << 9) | 1u); } // index << 18, junk elsewhere
+__device__ __forceinline__ int cell_in_block(uint32_t p) { return static_cast<int>((cell_in_block_shifted(p) >> 18) & 63u); }
+__device__ __forceinline__ bool cell_occupied(const RayState& r) { return (r.fine >> ((cell_in_block_shifted(r.p) >> 18) & 63u)) & 1ull; }
+// axis of the last move from its packed increment: +-1 = x, +-2^11 = y, +-2^22 = z, 0 = no move yet (-1).  (A zero
+// increment can only be selected for a direction with a zero component whose tmax of 1e6 is the smallest of the three:
+// impossible for a unit direction inside the grid.)
+__device__ __forceinline__ int move_axis(int last_step) {
+	const uint32_t a = static_cast<uint32_t>(last_step < 0 ? -last_step : last_step);
+	return a == 0u ? -1 : (a == 1u ? 0 : (a == (1u << 11) ? 1 : 2));
+}
 
 // voxel.cuh:136-189: clip against the world box, move onto it, set up the Amanatides-Woo state.
 // Returns the lane's next state: ST_OUTER / ST_CAND, or ST_NEED with r.hit = false when the ray misses the box.
@@ -242,7 +251,7 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 	r.ty = dir.y != 0.f ? (cby - origin.y) * ry : 1000000.f;
 	r.tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
 	r.dx = static_cast<float>(sx) * rx; r.dy = static_cast<float>(sy) * ry; r.dz = static_cast<float>(sz) * rz;
-	r.axis = -1;
+	r.last_step = 0;
 	load_block(sc, r); // inside the grid: never a border block
 	if (DBG) tally.index_loads++; // one per visited cell = the reference's index loads (algorithmic count)
 	return cell_occupied(r) ? ST_CAND : ST_OUTER;
@@ -258,18 +267,18 @@ __device__ __forceinline__ int outer_step(const DeviceScene& sc, RayState& r, Ta
 	const bool mx = tx < ty && tx < tz;
 	const bool my = ty <= tx && ty < tz; // mx implies !my
 	const bool mz = !(mx || my);
-	const uint32_t old = r.p;
 	const int step_x = r.sx, step_y = r.stepy, step_z = r.stepz;
-	const uint32_t np = old + static_cast<uint32_t>(mx ? step_x : (my ? step_y : step_z)); // pos += mask * step
-	r.p = np;
+	const int step = mx ? step_x : (my ? step_y : step_z);
+	r.p += static_cast<uint32_t>(step); // pos += mask * step
+	r.last_step = step;                 // identifies the axis of this move (see move_axis)
 	r.tx = tx + (mx ? r.dx : 0.f);
 	r.ty = ty + (my ? r.dy : 0.f);
 	r.tz = tz + (mz ? r.dz : 0.f);
-	r.axis = mx ? 0 : (my ? 1 : 2);
-	const uint32_t changed = old ^ np;
-	if (changed & kBlockBits) { // the move crossed a 4-aligned boundary (the world edge is one: exit test, voxel.cuh:256)
-		if (!load_block(sc, r)) return ST_NEED; // left the grid: miss (r.hit stays false)
-	}
+	// The block record is re-read on EVERY move, not only when the move crossed a block boundary: in a 64-lane wave some
+	// lane crosses one on practically every step, so the conditional version executes the same instructions plus the
+	// test and the branch (measured 2 % slower); consecutive reads of one record are L1 hits.  A border record means
+	// the ray has left the grid (the exit test of voxel.cuh:256).
+	if (!load_block(sc, r)) return ST_NEED; // miss (r.hit stays false)
 	if (DBG) tally.index_loads++;
 	return cell_occupied(r) ? ST_CAND : ST_OUTER;
 }
@@ -293,10 +302,11 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	BrickRegs brick;
 	brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
 	float new_distance = 0.f;
-	if (r.axis != -1) {
+	const int axis = move_axis(r.last_step);
+	if (axis != -1) {
 		r.n = mk(0.f, 0.f, 0.f);
-		if (r.axis == 0) { r.n.x = -static_cast<float>(sx); new_distance = r.tx - r.dx; }
-		else if (r.axis == 1) { r.n.y = -static_cast<float>(sy); new_distance = r.ty - r.dy; }
+		if (axis == 0) { r.n.x = -static_cast<float>(sx); new_distance = r.tx - r.dx; }
+		else if (axis == 1) { r.n.y = -static_cast<float>(sy); new_distance = r.ty - r.dy; }
 		else { r.n.z = -static_cast<float>(sz); new_distance = r.tz - r.dz; }
 	}
 	const int ddx = campos[0] - px, ddy = campos[1] - py, ddz = campos[2] - pz;
