@@ -278,9 +278,10 @@ __device__ __forceinline__ int outer_step(const DeviceScene& sc, RayState& r, Ta
 	// lane crosses one on practically every step, so the conditional version executes the same instructions plus the
 	// test and the branch (measured 2 % slower); consecutive reads of one record are L1 hits.  A border record means
 	// the ray has left the grid (the exit test of voxel.cuh:256).
-	if (!load_block(sc, r)) return ST_NEED; // miss (r.hit stays false)
-	if (DBG) tally.index_loads++;
-	return cell_occupied(r) ? ST_CAND : ST_OUTER;
+	const bool inside = load_block(sc, r); // false: left the grid, a miss (r.hit stays false; a border record's mask is 0)
+	if (DBG && inside) tally.index_loads++;
+	const bool occupied = static_cast<uint32_t>(r.fine >> ((cell_in_block_shifted(r.p) >> 18) & 63u)) & 1u;
+	return inside ? (occupied ? ST_CAND : ST_OUTER) : ST_NEED; // select, not branch: every path of this loop costs full issue
 }
 
 // voxel.cuh:200-247: the current cell holds a non-empty brick -- read its index word and resolve it.
