@@ -96,42 +96,50 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 	float tx = dir.x != 0.f ? (cbx - origin.x) * rx : 1000000.f;
 	float ty = dir.y != 0.f ? (cby - origin.y) * ry : 1000000.f;
 	float tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
-	px %= N; py %= N; pz %= N;
 	distance = 0.f;
-	int axis = -1;
-	// "& 7" / "& 63" only define what the reference leaves undefined (a negative start cell); no effect otherwise
+	// The walk cell is ONE register: three 5-bit fields, each holding (coordinate % N) + 8, so a coordinate that
+	// leaves [0, N) shows up as a change of its field's upper bits -- "still inside" is one AND + one compare for all
+	// three axes, a move is one add of a per-axis constant, and the loop below has a single exit condition (a divergent
+	// loop with several breaks spends more scalar instructions on exit-mask bookkeeping than vector ones on the walk).
+	// (`& (N - 1)` only defines what the reference leaves undefined, a negative start cell; no effect otherwise.)
+	constexpr uint32_t kOnes = 1u | (1u << 5) | (1u << 10);
+	constexpr uint32_t kGuard = (~static_cast<uint32_t>(N - 1) & 0x1Fu) * kOnes, kInside = 8u * kOnes;
+	uint32_t cell = ((static_cast<uint32_t>(px % N) & (N - 1)) | ((static_cast<uint32_t>(py % N) & (N - 1)) << 5) | ((static_cast<uint32_t>(pz % N) & (N - 1)) << 10)) + kInside;
+	const int step_x = sx, step_y = sy * 32, step_z = sz * 1024;
+	const int lds_lane = threadIdx.x;
+	auto test = [&](uint32_t c, unsigned long long slice) -> bool {
+		if (N == 8) return static_cast<uint32_t>(slice >> ((c & 7u) | ((c >> 2) & 0x38u))) & 1u;          // bit x + 8y of the z-slice
+		return (byte >> ((c & 1u) | ((c >> 4) & 2u) | ((c >> 8) & 4u))) & 1u;                                  // bit x + 2y + 4z of the LoD mask
+	};
 	if (N == 8) brick_to_lds(lds_brick, brick);
-	unsigned long long slice = N == 8 ? lds_brick[(pz & 7) * 256 + threadIdx.x] : 0ull;
+	unsigned long long slice = N == 8 ? lds_brick[((cell >> 10) & 7u) * 256 + lds_lane] : 0ull;
+	if (DBG) tally.voxel_steps++;
+	bool solid = test(cell, slice);
+	bool inside = true;
+	int last = 0; // packed increment of the last move: which axis it was
 	// at most 3N-2 cells lie on a line through an N^3 block; the bound only guards against NaN input
-	bool found = false;
-	for (int guard = 0; guard < 3 * N + 2; ++guard) {
-		if (DBG) tally.voxel_steps++;
-		bool solid;
-		if (N == 8) solid = (slice >> ((px + py * 8) & 63)) & 1ull;
-		else solid = (byte >> ((px + py * 2 + pz * 4) & 31)) & 1u;
-		if (solid) { found = true; break; } // resolved after the loop, once, for all lanes that hit
+	for (int guard = 3 * N + 1; !solid && inside && guard > 0; --guard) {
 		// select-style move (voxel.cuh:122-130); `t += mask ? delta : 0` is `tmax += mask * tdelta` for finite deltas
 		const bool mx = tx < ty && tx < tz;
 		const bool my = ty <= tx && ty < tz; // mx implies !my
 		const bool mz = !(mx || my);
-		axis = mx ? 0 : (my ? 1 : 2);
-		px += mx ? sx : 0;
-		py += my ? sy : 0;
-		pz += mz ? sz : 0;
-		const int c = mx ? px : (my ? py : pz);
-		const int s_sel = mx ? sx : (my ? sy : sz);
-		if (c == (s_sel > 0 ? N : -1)) break; // left the block
+		last = mx ? step_x : (my ? step_y : step_z);
+		cell += static_cast<uint32_t>(last);
+		inside = (cell & kGuard) == kInside; // false: left the block (the values below are then unused)
 		tx += mx ? dx : 0.f;
 		ty += my ? dy : 0.f;
 		tz += mz ? dz : 0.f;
-		if (N == 8 && mz) slice = lds_brick[pz * 256 + threadIdx.x];
+		if (N == 8) slice = lds_brick[((cell >> 10) & 7u) * 256 + lds_lane];
+		if (DBG && inside) tally.voxel_steps++;
+		solid = static_cast<bool>(static_cast<int>(inside) & static_cast<int>(test(cell, slice))); // no branch: (cell's fields are masked, any value is safe to test)
 	}
-	if (!found) return false;
-	if (axis > -1) { // voxel.cuh:114-118; a hit in the very first cell keeps distance 0 and the caller's normal
-		normal = mk(axis == 0 ? -static_cast<float>(sx) : 0.f, axis == 1 ? -static_cast<float>(sy) : 0.f, axis == 2 ? -static_cast<float>(sz) : 0.f);
-		distance = axis == 0 ? tx - dx : (axis == 1 ? ty - dy : tz - dz);
+	if (!solid) return false;
+	if (last != 0) { // voxel.cuh:114-118; a hit in the very first cell keeps distance 0 and the caller's normal
+		const int a = last < 0 ? -last : last; // 1 = x, 32 = y, 1024 = z
+		normal = mk(a == 1 ? -static_cast<float>(sx) : 0.f, a == 32 ? -static_cast<float>(sy) : 0.f, a == 1024 ? -static_cast<float>(sz) : 0.f);
+		distance = a == 1 ? tx - dx : (a == 32 ? ty - dy : tz - dz);
 	}
-	sub_id = px + py * N + pz * N * N;
+	sub_id = static_cast<int>((cell & (N - 1)) + ((cell >> 5) & (N - 1)) * N + ((cell >> 10) & (N - 1)) * N * N);
 	return true;
 }
 
