@@ -134,11 +134,11 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 		solid = static_cast<bool>(static_cast<int>(inside) & static_cast<int>(test(cell, slice))); // no branch: (cell's fields are masked, any value is safe to test)
 	}
 	if (!solid) return false;
-	if (last != 0) { // voxel.cuh:114-118; a hit in the very first cell keeps distance 0 and the caller's normal
-		const int a = last < 0 ? -last : last; // 1 = x, 32 = y, 1024 = z
-		normal = mk(a == 1 ? -static_cast<float>(sx) : 0.f, a == 32 ? -static_cast<float>(sy) : 0.f, a == 1024 ? -static_cast<float>(sz) : 0.f);
-		distance = a == 1 ? tx - dx : (a == 32 ? ty - dy : tz - dz);
-	}
+	// voxel.cuh:114-118, by select; a hit in the very first cell (no move) keeps distance 0 and the caller's normal
+	const int a = last < 0 ? -last : last; // 0 = no move, 1 = x, 32 = y, 1024 = z
+	normal = mk(a == 0 ? normal.x : (a == 1 ? -static_cast<float>(sx) : 0.f), a == 0 ? normal.y : (a == 32 ? -static_cast<float>(sy) : 0.f),
+				a == 0 ? normal.z : (a == 1024 ? -static_cast<float>(sz) : 0.f));
+	distance = a == 0 ? 0.f : (a == 1 ? tx - dx : (a == 32 ? ty - dy : tz - dz));
 	sub_id = static_cast<int>((cell & (N - 1)) + ((cell >> 5) & (N - 1)) * N + ((cell >> 10) & (N - 1)) * N * N);
 	return true;
 }
@@ -310,14 +310,12 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	const uint32_t index = sc.index_grid[flat];
 	BrickRegs brick;
 	brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
-	float new_distance = 0.f;
+	// voxel.cuh:202-206, by select: entry normal and entry distance from the axis of the last move; a ray that starts
+	// inside this cell (no move yet) keeps its normal and enters at distance 0
 	const int axis = move_axis(r.last_step);
-	if (axis != -1) {
-		r.n = mk(0.f, 0.f, 0.f);
-		if (axis == 0) { r.n.x = -static_cast<float>(sx); new_distance = r.tx - r.dx; }
-		else if (axis == 1) { r.n.y = -static_cast<float>(sy); new_distance = r.ty - r.dy; }
-		else { r.n.z = -static_cast<float>(sz); new_distance = r.tz - r.dz; }
-	}
+	const float new_distance = axis == 0 ? r.tx - r.dx : (axis == 1 ? r.ty - r.dy : (axis == 2 ? r.tz - r.dz : 0.f));
+	r.n = mk(axis == -1 ? r.n.x : (axis == 0 ? -static_cast<float>(sx) : 0.f), axis == -1 ? r.n.y : (axis == 1 ? -static_cast<float>(sy) : 0.f),
+			 axis == -1 ? r.n.z : (axis == 2 ? -static_cast<float>(sz) : 0.f));
 	const int ddx = campos[0] - px, ddy = campos[1] - py, ddz = campos[2] - pz;
 	const int lod2 = ddx * ddx + ddy * ddy + ddz * ddz;
 	float sub_distance = 0.f;
