@@ -87,37 +87,38 @@ static inline float comp(v3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.
 static inline int compi(i3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 
 /* ---------------------------------------------------------------- deterministic sin/cos
- * Spec (shared, by specification not by code, with brickmap_amd/csrc/detmath.h):
- *   xd = (double)x; k = (int)(xd*2/pi + (xd>=0 ? .5 : -.5)); r = (xd - k*PIO2_HI) - k*PIO2_LO
- *   fdlibm kernel polynomials on r, quadrant fix-up by k&3, results rounded to float. */
+ * Spec (shared, by specification not by code, with brickmap_amd/csrc/detmath.h), everything in fp32:
+ *   k = (int)(x*2/pi + (x>=0 ? .5 : -.5)); r = ((x - k*C1) - k*C2) - k*C3 with C1+C2+C3 = pi/2 (k*C1, k*C2 exact)
+ *   z = r*r; sin r = (((S3 z + S2) z + S1) z r) + r; cos r = (((K3 z + K2) z + K1) z z - z/2) + 1; quadrant by k&3.
+ * <= 1.5 ulp for |x| <= 2 pi.  The reference uses CUDA's sin()/cos() here (kernel.cu:102,296; sunsky.cu:183),
+ * which are specified to a couple of ulp only, so any sincos of that quality restates it. */
 static void orc_sincos_impl(float x, float* s_out, float* c_out) {
-	const double TWO_OVER_PI = 6.36619772367581382433e-01;
-	const double PIO2_HI = 1.57079632679489655800e+00;
-	const double PIO2_LO = 6.12323399573676603587e-17;
-	const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-				 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-				 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-	const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-				 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-				 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-	double xd = (double)x;
-	int k = (int)(xd * TWO_OVER_PI + (xd >= 0.0 ? 0.5 : -0.5));
-	double kd = (double)k;
-	double r = (xd - kd * PIO2_HI) - kd * PIO2_LO;
-	double z = r * r;
-	double ps = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
-	double sr = r + (r * z) * ps;
-	double pc = C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6))));
-	double cr = (1.0 - 0.5 * z) + (z * z) * pc;
-	double s, c;
+	static const float TWO_OVER_PI = 0.6366197723675814f;
+	static const float PIO2_1 = 1.5703125f, PIO2_2 = 4.837512969970703125e-4f, PIO2_3 = 7.54978995489188e-8f;
+	static const float S1 = -1.6666654611e-1f, S2 = 8.3321608736e-3f, S3 = -1.9515295891e-4f;
+	static const float K1 = 4.166664568298827e-2f, K2 = -1.388731625493765e-3f, K3 = 2.443315711809948e-5f;
+	float half = x >= 0.0f ? 0.5f : -0.5f;
+	int k = (int)(x * TWO_OVER_PI + half);
+	float kf = (float)k;
+	float r = x - kf * PIO2_1;
+	r = r - kf * PIO2_2;
+	r = r - kf * PIO2_3;
+	float z = r * r;
+	float ps = S3 * z + S2;
+	ps = ps * z + S1;
+	float sr = (ps * z) * r + r;
+	float pc = K3 * z + K2;
+	pc = pc * z + K1;
+	float cr = ((pc * z) * z - 0.5f * z) + 1.0f;
+	float s, c;
 	switch (k & 3) {
 	case 0: s = sr; c = cr; break;
 	case 1: s = cr; c = -sr; break;
 	case 2: s = -sr; c = -cr; break;
 	default: s = -cr; c = sr; break;
 	}
-	*s_out = (float)s;
-	*c_out = (float)c;
+	*s_out = s;
+	*c_out = c;
 }
 ORC_API void orc_sincos(int n, const float* x, float* s, float* c) {
 	for (int i = 0; i < n; i++) orc_sincos_impl(x[i], &s[i], &c[i]);
