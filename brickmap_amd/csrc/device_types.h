@@ -79,6 +79,7 @@ struct FrameConstants {
 	float rayleigh[3];     // rayleighAtX
 	float mie[3];          // mieAtX = totalMie(...) * mieCoefficient
 	float total[3];        // rayleighAtX + mieAtX
+	float inv_total[3];    // 1 / total
 	float mixf;            // clamp(pow(1 - dot(up, sunDirection), 5), 0, 1)
 	// frame
 	int width, height;

@@ -95,6 +95,7 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp,
 		fc->rayleigh[i] = rayleigh[i];
 		fc->mie[i] = total_mie * 0.005f;
 		fc->total[i] = fc->rayleigh[i] + fc->mie[i];
+		fc->inv_total[i] = 1.0f / fc->total[i];
 	}
 	const float m = std::pow(1.0f - dot3(sky_up, sun), 5.0f);
 	fc->mixf = std::min(std::max(m, 0.0f), 1.0f);
