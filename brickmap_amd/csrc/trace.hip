@@ -45,6 +45,9 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_QUORUM_DIV
 #define BM_QUORUM_DIV 4
 #endif
+#ifndef BM_QUORUM_SHADE_DIV
+#define BM_QUORUM_SHADE_DIV BM_QUORUM_DIV
+#endif
 #ifndef BM_QUORUM_CONN_DIV
 #define BM_QUORUM_CONN_DIV 8
 #endif
@@ -167,8 +170,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		// Policy: an expensive phase runs once a quarter of the live lanes wait for it, the cheap connect phase
 		// once an eighth does; otherwise the DDA keeps moving.  With no lane left in the DDA the largest group runs.
 		const int quorum = (live + BM_QUORUM_DIV - 1) / BM_QUORUM_DIV, quorum_conn = (live + BM_QUORUM_CONN_DIV - 1) / BM_QUORUM_CONN_DIV;
+		const int quorum_shade = (live + BM_QUORUM_SHADE_DIV - 1) / BM_QUORUM_SHADE_DIV;
 		int phase; // 0 = A (DDA moves), 1 = B (candidates), 2 = C (shade / generate), 3 = D (connect)
-		if (nC >= quorum) phase = 2;
+		if (nC >= quorum_shade) phase = 2;
 		else if (nB >= quorum) phase = 1;
 		else if (nD >= quorum_conn) phase = 3;
 		else if (nA > 0) phase = 0;
