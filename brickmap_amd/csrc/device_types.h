@@ -10,11 +10,12 @@ namespace bm {
 //   index_grid  u32[supercells * 4096]   supercell-major; supercell id = sx + sy*sg_xy + sz*sg_xy^2,
 //                                         word (lx + 16*ly + 256*lz) inside it  -- the reference's
 //                                         addressing (voxel.cuh:197-198) minus its pointer table
-//   super_info  16 B per supercell        {u64 coarse occupancy, u32 brick_base, u32 0}: bit
-//                                         (bx + 4*by + 16*bz) of `coarse` says whether the 4x4x4-brick
-//                                         block (bx,by,bz) of the supercell holds any non-empty brick;
-//                                         brick_base = first arena slot of the supercell (exclusive
-//                                         prefix sum of non-empty brick counts; replaces Brick**)
+//   super_info  16 B per supercell        {u64 coarse, u32 brick_base, u32 0}: brick_base = first arena slot of the
+//                                         supercell (exclusive prefix sum of non-empty brick counts; replaces
+//                                         Brick**), read by the upload kernel.  `coarse` (which of its 4x4x4
+//                                         blocks hold bricks) is no longer read by any kernel: the walk used it
+//                                         to skip the records of empty blocks until that turned out to cost more
+//                                         instructions than the loads it saved.
 //   block_grid  16 B per 4x4x4-brick block {u64 mask, u32 base, u32 outside}, a dense x-fastest 3-D array over the
 //                                         whole grid plus a one-block border: mask bit (cx + 4*cy + 16*cz) =
 //                                         "index word of that brick is non-zero".  Static (residency flags never
@@ -27,7 +28,7 @@ namespace bm {
 //                                         a ray that steps off the grid reads one, which IS the reference's
 //                                         per-step exit test (voxel.cuh:256) -- the walk needs no bounds
 //                                         compare, no supercell bookkeeping and one independent 16-byte load
-//                                         per block boundary crossed.
+//                                         per move (re-read every step; consecutive reads are L1 hits).
 //   brick_arena 64 B * total_bricks      exact-fit pool, every brick has a fixed home slot; the 12-bit slot of
 //                                         a device index word is that slot relative to brick_base
 //   load_queue  int3[queue_cap] + count  brick-request ring (voxel.cuh:228-245)

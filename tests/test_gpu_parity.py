@@ -219,6 +219,27 @@ def test_non_cubic_world(bm, orc, torch_cuda):
     scene.close()
 
 
+@pytest.mark.parametrize("dims,pos,angles", [
+    ((128, 7936), (40.0, 40.0, 5900.0), (0.4, -1.5)),      # tallest world the packed cell register allows (992 bricks): down the shaft
+    ((128, 7936), (-900.0, 64.0, 3500.0), (1.5, 0.05)),    # camera outside, looking across the column below the terrain top
+    ((8192, 128), (8000.0, 8100.0, 120.0), (3.9, -0.12)),  # widest world (1024 bricks): the far corner, looking back
+])
+def test_extreme_world_dimensions(dims, pos, angles, bm, orc, torch_cuda):
+    """The packed brick cell (11 + 11 + 10 bits, biased) at the ends of its range, the bordered block grid at the far faces."""
+    G, GH = dims
+    scene = bm.Scene(G, GH, device=0).generate().preload_all()
+    w = orc.World(G, GH, threads=os.cpu_count() or 1)
+    w.reset_device(True)
+    cam = bm.Camera(position=pos, horizontal_angle=angles[0], vertical_angle=angles[1]).update()
+    ocam = orc.make_camera(cam.position, cam.direction)
+    acc, dbg = gpu_render(bm, torch_cuda, scene, cam, bm.FrameParams(96, 64, spp=1, max_bounces=3))
+    oacc, odbg, _, _ = w.render(ocam, orc.make_frame(96, 64, spp=1, max_bounces=3), threads=os.cpu_count() or 1)
+    assert np.array_equal(dbg, odbg)
+    assert (dbg[..., 1] != 0).mean() > 0.02  # the view does hit the world
+    assert_radiance(acc, oacc)
+    scene.close()
+
+
 def test_streaming_first_frame_and_steady_state(bm, orc, torch_cuda):
     """Reference initial residency: nothing loaded.  Frame 1 treats every unloaded brick as solid and
     requests it (deterministic image, deterministic request SET); at steady state the image equals
@@ -368,6 +389,9 @@ def test_errors_are_reported_not_fatal(bm, torch_cuda):
     L = _lib.load()
     h = C.c_void_p()
     assert L.bm_scene_create(0, 100, 128, C.byref(h)) == 10001 and b"multiples of 128" in L.bm_last_error_string()
+    # the walk packs a brick cell into 11 + 11 + 10 bits: larger worlds are refused, not mis-traced
+    assert L.bm_scene_create(0, 8192 + 128, 128, C.byref(h)) == 10001 and b"not supported" in L.bm_last_error_string()
+    assert L.bm_scene_create(0, 1024, 8064, C.byref(h)) == 10001 and b"not supported" in L.bm_last_error_string()
     s = bm.Scene(128, 128, device=0)
     with pytest.raises(bm.BrickmapError):
         s.preload_all()  # not generated yet
