@@ -79,8 +79,7 @@ struct FrameConstants {
 	float sunE;            // SunIntensity(dot(sunDirection, up))
 	float rayleigh[3];     // rayleighAtX
 	float mie[3];          // mieAtX = totalMie(...) * mieCoefficient
-	float total[3];        // rayleighAtX + mieAtX
-	float inv_total[3];    // 1 / total
+	float inv_total[3];    // 1 / (rayleighAtX + mieAtX)
 	float mixf;            // clamp(pow(1 - dot(up, sunDirection), 5), 0, 1)
 	// frame
 	int width, height;
@@ -89,7 +88,7 @@ struct FrameConstants {
 	uint32_t flags;
 	int band_rows, shard_rank, shard_count, local_rows;
 	// launch geometry
-	int tiles_x, tiles_y, stripe_w; // 16x16-pixel tiles; stripe_w = tile columns per XCD
+	int tiles_x, tiles_y; // 16x16-pixel tiles covering this shard's rows
 };
 
 struct DeviceCounters { // v: same order as bm_counters; sched: same order as bm_sched_stats

@@ -94,8 +94,7 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp,
 		const float total_mie = (std::pow((2.0f * kPi) / lambda[i], expo) * mie_scale) * K[i];
 		fc->rayleigh[i] = rayleigh[i];
 		fc->mie[i] = total_mie * 0.005f;
-		fc->total[i] = fc->rayleigh[i] + fc->mie[i];
-		fc->inv_total[i] = 1.0f / fc->total[i];
+		fc->inv_total[i] = 1.0f / (fc->rayleigh[i] + fc->mie[i]);
 	}
 	const float m = std::pow(1.0f - dot3(sky_up, sun), 5.0f);
 	fc->mixf = std::min(std::max(m, 0.0f), 1.0f);
@@ -107,7 +106,6 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp,
 	fc->local_rows = bm_local_rows(fp);
 	fc->tiles_x = (fp->width + 15) / 16;
 	fc->tiles_y = (fc->local_rows + 15) / 16;
-	fc->stripe_w = (fc->tiles_x + 7) / 8;
 	return 0;
 }
 

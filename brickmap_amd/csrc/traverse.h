@@ -146,12 +146,13 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 // ---- brick-grid DDA (voxel.cuh:135-261), split into the three pieces the wave scheduler interleaves
 //
 // The reference reads one 32-bit index word per visited cell (two dependent loads through its pointer
-// table).  ~96 % of those words are zero (air), so the walk consults a two-level occupancy summary kept
-// in registers -- a 64-bit mask of the current 4x4x4-brick block and a 64-bit mask of the current
-// supercell's blocks (DeviceScene) -- and touches the index grid only at cells known to be non-empty.
-// Masks are re-read only when the walk crosses a block / supercell boundary, and because the world edge
-// is a supercell boundary the reference's per-step exit test (voxel.cuh:256) moves into that rare path too.
+// table).  ~96 % of those words are zero (air), so the walk consults the 64-bit occupancy mask of the cell's
+// 4x4x4-brick block (DeviceScene::block_grid, a dense bordered array) and touches the index grid only at cells
+// known to be non-empty.  A border record of that array is the reference's per-step exit test (voxel.cuh:256).
 // The per-cell arithmetic (axis choice, tmax accumulation) is the reference's, step for step.
+// Everything in the move is straight-line, select-style code: in a 64-lane wave every branch of a hot loop is
+// taken by some lane on almost every iteration, so a rarely-needed path costs its full instruction count anyway
+// ("Why the bookkeeping mattered").
 struct RayState {
 	f3 o, d;            // origin (brick units once set up) and direction
 	float tx, ty, tz;   // tmax
@@ -167,12 +168,11 @@ struct RayState {
 	bool hit;
 };
 
-enum : int { ST_NEED = 0, ST_OUTER = 1, ST_CAND = 2, ST_FIN = 3 };
+enum : int { ST_NEED = 0, ST_OUTER = 1, ST_CAND = 2 };
 
 // Packed brick cell.  The three coordinates share one register, biased by one supercell (16) so that the cell just
 // outside the grid on the negative side is representable (15) and a move never borrows across fields: a move is ONE
-// add of a per-axis constant, and "did this move cross a 4-brick block / 16-brick supercell boundary" is a test of
-// the bits that changed.  x, y: 11 bits (grids up to 1024 bricks wide), z: 10 bits (up to 992 high); Scene::init checks.
+// add of a per-axis constant.  x, y: 11 bits (grids up to 1024 bricks wide), z: 10 bits (up to 992 high); Scene::init checks.
 constexpr uint32_t kCellBias = 16u;
 __device__ __forceinline__ uint32_t pack_cell(int x, int y, int z) {
 	return (static_cast<uint32_t>(x) + kCellBias) | ((static_cast<uint32_t>(y) + kCellBias) << 11) | ((static_cast<uint32_t>(z) + kCellBias) << 22);
