@@ -4,6 +4,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 
@@ -96,3 +97,17 @@ def test_cpp_mirror_example_builds():
     r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "examples")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert os.path.exists(os.path.join(ROOT, "examples", "headless_main"))
+
+
+def test_cpp_mirror_header_compiles_standalone(tmp_path):
+    """include/brickmap.hpp + the headless example are plain C++17 against the C-ABI header: no HIP, no torch."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = os.path.join(ROOT, "examples", "headless_main.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", src])
+    # the C-ABI header itself is C: it must also compile as C11
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include "brickmap.h"\nint main(void) { bm_frame_params p; (void)p; return sizeof(bm_camera) ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(probe)])
