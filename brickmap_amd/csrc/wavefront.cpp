@@ -1,6 +1,7 @@
 // wavefront.cpp -- see wavefront.h
 #include "wavefront.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -34,7 +35,7 @@ int Wavefront::init() {
 	BM_HIP(hipMemset(d_counters_, 0, 2 * sizeof(DeviceCounters)));
 	for (auto& e : ev_) BM_HIP(hipEventCreate(&e));
 	for (int c = 0; c < 2; ++c)
-		for (int i = 0; i < 2; ++i) blocks_per_cu_[c][i] = wavefront_blocks_per_cu(c != 0, i != 0);
+		for (int i = 0; i < 2; ++i) blocks_per_cu_[c][i] = std::min(wavefront_blocks_per_cu(c != 0, i != 0), kMaxBlocksPerCu);
 	if (const char* cap = std::getenv("BM_WF_BLOCKS_PER_CU")) { // experiment knob: fewer resident waves per SIMD
 		const int n = std::atoi(cap);
 		for (int c = 0; c < 2; ++c)
