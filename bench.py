@@ -7,10 +7,12 @@ A "step" is one launch of the path-trace kernel over the workload's frame: `spp`
 (primary + up to max_bounces bounces, one shadow ray per hit) for every pixel of this rank's rows,
 with the scene already resident in HBM.  N = 1 runs BASELINE.json configs[1]:
 1920x1080, 1 spp, 4-bounce (MAX_BOUNCES = 3 -> 4 segments), 8x8x8 superchunks, all bricks resident.
-N > 1 keeps the per-GPU work fixed (weak scaling): the frame is split into interleaved 16-row
-bands, every rank traces N*spp samples for its H/N rows, then the packed bands are gathered to
-rank 0 over RCCL (brickmap_amd/dist.py); the gather of frame i overlaps the tracing of frame i+1 and every gather,
-including the last one, completes inside the timed region.
+N > 1 keeps the per-GPU work fixed (weak scaling) by sharding the SAMPLES: every rank traces the full frame with its
+own `spp` sample indices of each pixel (N*spp samples per pixel and step in total), then the N float4 frames are
+summed onto rank 0 over RCCL (brickmap_amd/dist.py FrameReducer); the reduction of frame i overlaps the tracing of
+frame i+1 and every reduction, including the last one, completes inside the timed region.  (Sharding the pixels
+instead -- row bands + gather, also in dist.py -- gives a bit-identical image but leaves each rank N*spp samples on
+1/N of the rows, a launch shape that costs the persistent kernel 1.2x / 1.5x / 2.5x at N = 2 / 4 / 8.)
 
 metric: Mrays/s = width * height * spp_total * segments / seconds  (nominal rays).
 The line also carries `roofline` (algorithmic bytes of the kernel / its HIP-event duration against
@@ -85,8 +87,7 @@ def main():
     W, H, spp, max_bounces, n_super, streaming = workload(args.workload)
     G = 128 * n_super
     segments = max_bounces + 1
-    band = bm.dist.DEFAULT_BAND_ROWS if world > 1 else H
-    spp_step = spp * world  # weak scaling: N x the samples, 1/N of the rows per rank
+    spp_step = spp * world  # weak scaling: N x the samples per pixel and step, each rank the full frame with its own sample slice
 
     # ---- scene replica on this GPU (world build is CPU plumbing and is not timed)
     t0 = time.time()
@@ -98,19 +99,18 @@ def main():
         scene.preload_all()
     build_s = time.time() - t0
     cam = bm.Camera(position=(G / 2, G / 8, 0.8 * G), horizontal_angle=0.8, vertical_angle=-0.5).update()
-    state = bm.State(W, H, device=local_rank, band_rows=band, shard_rank=rank, shard_count=world)
+    state = bm.State(W, H, device=local_rank)
     accum = state.blit_buffer
     if args.schedule == "wavefront":
         if world != 1:
             raise SystemExit("--schedule wavefront does not shard (replicas only): run it with --gpus 1")
         return bench_wavefront(args, bm, torch, np, scene, cam, accum, W, H, max_bounces, n_super, G, streaming, build_s)
 
-    def params(step, flags=0):
-        return bm.FrameParams(W, H, spp=spp_step, sample_base=step * spp_step, max_bounces=max_bounces, flags=flags,
-                              band_rows=band, shard_rank=rank, shard_count=world)
+    def params(step, flags=0):  # rank r owns samples [step*N*spp + r*spp, ... + spp) of every pixel
+        return bm.FrameParams(W, H, spp=spp, sample_base=(step * world + rank) * spp, max_bounces=max_bounces, flags=flags)
 
-    # N > 1: the gather of frame i runs on RCCL's stream while frame i+1 is being traced (one gather in flight)
-    gatherer = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev) if world > 1 else None
+    # N > 1: the reduction of frame i runs on RCCL's stream while frame i+1 is being traced (one reduction in flight)
+    gatherer = bm.dist.FrameReducer(H, W, device=dev) if world > 1 else None
 
     def one_step(step):
         scene.render(cam, params(step), accum)
@@ -118,7 +118,7 @@ def main():
             scene.process_load_queue()
         if gatherer is not None:
             gatherer.finish()      # frame step-1 is complete on rank 0
-            gatherer.start(accum)  # snapshot + asynchronous gather of this frame
+            gatherer.start(accum)  # snapshot + asynchronous sum-reduction of this frame
         return accum
 
     if streaming:  # reach streaming steady state before anything is timed
@@ -140,7 +140,7 @@ def main():
     for i in range(args.steps):
         one_step(args.warmup + i)
     if gatherer is not None:
-        gatherer.finish()  # the last frame's gather is inside the timed region
+        gatherer.finish()  # the last frame's reduction is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -190,7 +190,7 @@ def main():
                         f"{segments} segments/path, {n_super}^3 superchunks ({G}^3 voxels), "
                         + ("brick streaming at steady state" if streaming else "all bricks pre-loaded"),
             "width": W, "height": H, "spp_per_step": spp_step, "segments": segments, "world_voxels": G,
-            "sharding": f"{world} x interleaved {band}-row bands + RCCL gather" if world > 1 else "single GPU",
+            "sharding": f"{world} x sample shards (every rank the full frame, its own {spp} of the {spp_step} samples) + RCCL sum-reduce to rank 0" if world > 1 else "single GPU",
             "camera": {"position": list(cam.position), "angles": [0.8, -0.5]},
             "world_build_s": round(build_s, 2),
         },

@@ -1,12 +1,21 @@
-"""Multi-GPU sharding of the frame: interleaved row bands + one gather over RCCL/xGMI.
+"""Multi-GPU sharding of the path-trace job: two decompositions, one exchange each, over RCCL/xGMI.
 
-The reference is single-GPU (no collective anywhere).  Pixels are independent, so
-the frame is split into row bands dealt round-robin to the ranks (band b belongs to rank
-b % world): each rank holds a full scene replica, renders its rows into a packed local float4
-buffer with RNG streams keyed on the *global* pixel index (so an N-rank image is bit-identical
-to the 1-rank image), and the only exchange is one gather of the packed bands to rank 0
-(`torch.distributed.gather` = grouped ncclSend/ncclRecv on the nccl/RCCL backend, one xGMI
-link per peer into the root).  No collective sits on the data path of the render itself.
+The reference is single-GPU (no collective anywhere).  Every (pixel, sample) pair is an
+independent path and every rank holds a full scene replica, so the job can be cut either way:
+
+* by PIXELS -- interleaved row bands (band b belongs to rank b % world; `shard_rows`, `gather_frame`,
+  `FrameGatherer`): each rank renders its rows into a packed local float4 buffer with RNG streams keyed on the
+  *global* pixel index, so an N-rank image is bit-identical to the 1-rank image; the exchange is one gather of the
+  packed bands to rank 0 (grouped ncclSend/ncclRecv, one xGMI link per peer into the root).  This is the
+  latency decomposition: one frame finishes N times sooner.
+* by SAMPLES -- every rank renders the full frame with its own slice of the sample indices (`sample_base` of
+  bm_frame_params; `FrameReducer`): the exchange is one sum-reduction of the float4 frames to rank 0.  This is the
+  throughput decomposition (N x the samples per frame): each rank's launch keeps the single-GPU shape -- the
+  persistent kernel needs many more pixels than lanes to keep its waves full, and N x spp samples on 1/N of the rows
+  cost 1.2x / 1.5x / 2.5x the single-GPU kernel time at N = 2 / 4 / 8 (tools/shard_time.py) -- so `bench.py` uses it.
+  The sum of N partial frames differs from one N x spp render only in floating-point association (~1e-7 relative).
+
+No collective sits on the data path of the render itself.
 """
 import numpy as np
 
@@ -113,3 +122,46 @@ class FrameGatherer:
             if self.rows[r].numel():
                 self.out.index_copy_(0, self.rows[r], self.recv[r][: self.counts[r]])
         return self.out.to(self.out_device)
+
+
+class FrameReducer:
+    """Sample-sharded frames: every rank holds a full [height, W, C] accumulation of ITS samples; `start(local)`
+    snapshots it and launches the sum-reduction to `dst` asynchronously (RCCL's stream, behind the work already queued on
+    the current stream) so that it overlaps the next frame's rendering; `finish()` waits for it and returns the summed
+    frame on `dst` (None elsewhere; the returned tensor is reused by the next start()).  At most one reduction in flight."""
+
+    def __init__(self, height, width, channels=4, dtype=None, device=None, group=None, dst=0):
+        import torch
+        import torch.distributed as dist
+        self.group, self.dst = group, dst
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.out_device = torch.device(device) if device is not None else torch.device("cpu")
+        # gloo (CPU tests / single-GPU smoke runs) reduces host tensors: stage through host memory there
+        self.stage_on_cpu = self.world > 1 and dist.get_backend(group) == "gloo"
+        buf_device = torch.device("cpu") if self.stage_on_cpu else self.out_device
+        self.buf = torch.zeros((height, width, channels), dtype=dtype or torch.float32, device=buf_device)
+        self.work = None
+        self.local = None
+
+    def start(self, local):
+        import torch.distributed as dist
+        assert self.work is None and self.local is None, "finish() the previous reduction first"
+        assert tuple(local.shape) == tuple(self.buf.shape)
+        if self.world == 1:
+            self.local = local
+            return
+        self.buf.copy_(local)  # snapshot: the caller may keep accumulating into `local`
+        self.work = dist.reduce(self.buf, dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        if self.world == 1:
+            out, self.local = self.local, None
+            return out
+        if self.work is None:
+            return None
+        self.work.wait()
+        self.work = None
+        if self.rank != self.dst:
+            return None
+        return self.buf.to(self.out_device)

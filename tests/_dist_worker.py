@@ -47,6 +47,20 @@ def main():
         print("PIPE_OK", world)
     else:
         assert first is None and second is None
+    # sample sharding: every rank renders the full frame with its own sample indices; the frames are summed on rank 0
+    mine = np.zeros((H, W, 4), np.float32)
+    w.render(cam, oracle.make_frame(W, H, spp=2, sample_base=2 * rank), accum=mine, want_dbg=False)
+    red = bdist.FrameReducer(H, W, device="cpu")
+    red.start(torch.from_numpy(mine))
+    total = red.finish()
+    if rank == 0:
+        want_all, _, _, _ = w.render(cam, oracle.make_frame(W, H, spp=2 * world), want_dbg=False)
+        got = total.numpy()
+        assert np.array_equal(got[..., 3], want_all[..., 3])  # terminated-path counts are integers: exact
+        assert np.allclose(got, want_all, rtol=1e-5, atol=1e-7), "sum of the sample shards differs from the single render"
+        print("SAMPLES_OK", world)
+    else:
+        assert total is None
     dist.barrier()
     dist.destroy_process_group()
 

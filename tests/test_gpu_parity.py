@@ -327,6 +327,21 @@ def test_sharded_equals_unsharded_and_accumulation(bm, orc, torch_cuda, scene256
     assert np.array_equal(acc.cpu().numpy(), full)
 
 
+def test_sample_sharded_frames_sum_to_the_single_render(bm, orc, torch_cuda, scene256):
+    """The throughput decomposition bench.py uses at N > 1: rank r renders the FULL frame with samples
+    [r*spp, (r+1)*spp); the sum of the N frames is the N*spp render up to floating-point association."""
+    torch = torch_cuda
+    cam, _ = cameras(bm, orc, 256)
+    W, H, spp, N = 96, 64, 2, 4
+    whole, dbg = gpu_render(bm, torch, scene256, cam, bm.FrameParams(W, H, spp=spp * N, max_bounces=3))
+    total = np.zeros_like(whole)
+    for r in range(N):
+        part, _ = gpu_render(bm, torch, scene256, cam, bm.FrameParams(W, H, spp=spp, sample_base=r * spp, max_bounces=3), want_dbg=False)
+        total += part
+    assert np.array_equal(total[..., 3], whole[..., 3]) and whole[..., 3].min() == spp * N
+    assert_radiance(total, whole)
+
+
 def test_launch_kernels_mirror_and_resolve(bm, orc, torch_cuda, scene256, world256):
     """The reference-shaped call sequence: State + launch_kernels per frame, then the resolve ("blit")."""
     torch = torch_cuda
