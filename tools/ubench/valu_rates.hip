@@ -1,0 +1,86 @@
+// valu_rates.hip -- issue cost of the VALU instructions the walk loops are made of, on gfx950.
+// Each kernel runs ITER iterations of 16 independent instances of one instruction per wave; the grid fills every
+// SIMD with W waves.  Reported: SIMD cycles per wave-instruction = W waves share one SIMD's issue.
+//   build: hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_rates.hip -o scratch/valu_rates   run: scratch/valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP16(X) X X X X X X X X X X X X X X X X
+constexpr int ITER = 4096;
+
+#define KERNEL(name, ASM)                                                                                   \
+	__global__ __launch_bounds__(256) void name(float* out, float a, float b) {                             \
+		float v0 = a + threadIdx.x, v1 = b, v2 = a * 2, v3 = b * 3;                                        \
+		unsigned u0 = threadIdx.x, u1 = blockIdx.x + 7;                                                    \
+		unsigned long long w = threadIdx.x * 0x100000001ull;                                               \
+		for (int i = 0; i < ITER; ++i) { REP16(asm volatile(ASM : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(u0), "+v"(u1), "+v"(w) : : "vcc", "scc", "s10", "s11");) } \
+		out[blockIdx.x * 256 + threadIdx.x] = v0 + v1 + v2 + v3 + u0 + u1 + (float)w;                      \
+	}
+
+KERNEL(k_add_f32, "v_add_f32 %0, %1, %0\n")
+KERNEL(k_fma_f32, "v_fma_f32 %0, %1, %2, %0\n")
+KERNEL(k_pk_add_f32, "v_pk_add_f32 %6, %6, %6\n")
+KERNEL(k_add_u32, "v_add_u32 %4, %5, %4\n")
+KERNEL(k_add3_u32, "v_add3_u32 %4, %5, %4, %5\n")
+KERNEL(k_and_or, "v_and_or_b32 %4, %5, %4, %5\n")
+KERNEL(k_bfe, "v_bfe_u32 %4, %4, 2, 9\n")
+KERNEL(k_mul24, "v_mul_u32_u24 %4, %5, %4\n")
+KERNEL(k_mul_lo, "v_mul_lo_u32 %4, %5, %4\n")
+KERNEL(k_lshr64, "v_lshrrev_b64 %6, %4, %6\n")
+KERNEL(k_cmp_vcc, "v_cmp_lt_f32 vcc, %0, %1\n")
+KERNEL(k_cmp_sgpr, "v_cmp_lt_f32 s[10:11], %0, %1\n")
+KERNEL(k_cndmask_vcc, "v_cndmask_b32 %0, %1, %2, vcc\n")
+KERNEL(k_cndmask_sgpr, "v_cndmask_b32 %0, %1, %0, s[10:11]\n")
+KERNEL(k_cmp_cnd, "v_cmp_lt_f32 vcc, %0, %1\nv_cndmask_b32 %2, %3, %2, vcc\n")
+KERNEL(k_bitop3, "v_bitop3_b32 %4, %4, %5, %4 bitop3:0x48\n")
+KERNEL(k_mov, "v_mov_b32 %0, %1\n")
+KERNEL(k_salu, "s_and_b64 s[10:11], s[10:11], vcc\n")
+KERNEL(k_and, "v_and_b32 %4, %5, %4\n")
+KERNEL(k_lshr32, "v_lshrrev_b32 %4, 3, %4\n")
+KERNEL(k_lshl_or, "v_lshl_or_b32 %4, %5, 3, %4\n")
+KERNEL(k_lshl_add, "v_lshl_add_u32 %4, %5, 3, %4\n")
+KERNEL(k_mad24, "v_mad_u32_u24 %4, %5, %4, %5\n")
+KERNEL(k_mul_f32, "v_mul_f32 %0, %1, %0\n")
+KERNEL(k_min_f32, "v_min_f32 %0, %1, %0\n")
+KERNEL(k_min3_f32, "v_min3_f32 %0, %1, %2, %0\n")
+KERNEL(k_cmp_eq_u32, "v_cmp_eq_u32 vcc, %4, %5\n")
+KERNEL(k_cvt, "v_cvt_f32_i32 %0, %4\n")
+KERNEL(k_rcp, "v_rcp_f32 %0, %0\n")
+KERNEL(k_bcnt, "v_bcnt_u32_b32 %4, %5, %4\n")
+KERNEL(k_fma_f64, "v_fma_f64 %6, %6, %6, %6\n")
+
+template <typename K>
+static void run(const char* name, K kernel, int per_iter, float* out, int cus) {
+	for (int waves : {4, 8}) {
+		const int blocks = cus * waves; // 256 threads = 4 waves = one per SIMD
+		hipEvent_t e0, e1;
+		hipEventCreate(&e0); hipEventCreate(&e1);
+		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, 1.0f, 2.0f);
+		hipEventRecord(e0);
+		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, 0, out, 1.0f, 2.0f);
+		hipEventRecord(e1);
+		hipEventSynchronize(e1);
+		float ms = 0;
+		hipEventElapsedTime(&ms, e0, e1);
+		const double insts_per_simd = static_cast<double>(ITER) * 16 * per_iter * waves;
+		const double cycles = ms * 1e-3 * 2.4e9; // nominal 2.4 GHz
+		std::printf("%-14s %d waves/SIMD: %.2f SIMD-cycles per wave-instruction\n", name, waves, cycles / insts_per_simd);
+		hipEventDestroy(e0); hipEventDestroy(e1);
+	}
+}
+
+int main() {
+	hipDeviceProp_t prop;
+	hipGetDeviceProperties(&prop, 0);
+	const int cus = prop.multiProcessorCount;
+	float* out;
+	hipMalloc(&out, sizeof(float) * 256 * cus * 8);
+#define RUN(k, n) run(#k, k, n, out, cus)
+	RUN(k_add_f32, 1); RUN(k_fma_f32, 1); RUN(k_pk_add_f32, 1); RUN(k_add_u32, 1); RUN(k_add3_u32, 1); RUN(k_and_or, 1); RUN(k_bfe, 1);
+	RUN(k_mul24, 1); RUN(k_mul_lo, 1); RUN(k_lshr64, 1); RUN(k_cmp_vcc, 1); RUN(k_cmp_sgpr, 1); RUN(k_cndmask_vcc, 1); RUN(k_cndmask_sgpr, 1);
+	RUN(k_cmp_cnd, 2); RUN(k_bitop3, 1); RUN(k_mov, 1); RUN(k_salu, 1);
+	RUN(k_and, 1); RUN(k_lshr32, 1); RUN(k_lshl_or, 1); RUN(k_lshl_add, 1); RUN(k_mad24, 1); RUN(k_mul_f32, 1); RUN(k_min_f32, 1); RUN(k_min3_f32, 1);
+	RUN(k_cmp_eq_u32, 1); RUN(k_cvt, 1); RUN(k_rcp, 1); RUN(k_bcnt, 1); RUN(k_fma_f64, 1);
+	return 0;
+}
