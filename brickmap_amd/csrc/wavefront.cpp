@@ -9,7 +9,7 @@
 namespace bm {
 
 Wavefront::~Wavefront() {
-	if (hipSetDevice(scene_->device()) != hipSuccess) return;
+	if (hipSetDevice(device_) != hipSuccess) return;
 	(void)hipDeviceSynchronize();
 	(void)hipFree(d_work_); (void)hipFree(d_next_); (void)hipFree(d_shadow_); (void)hipFree(d_state_); (void)hipFree(d_block_counts_); (void)hipFree(d_counters_);
 	(void)hipFree(d_frame_constants_);
@@ -19,7 +19,7 @@ Wavefront::~Wavefront() {
 
 int Wavefront::init() {
 	if (queue_size_ == 0 || queue_size_ > (1u << 30)) { set_error("bad queue size"); return BM_EINVAL; }
-	BM_HIP(hipSetDevice(scene_->device()));
+	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipMalloc(&d_work_, static_cast<size_t>(queue_size_) * sizeof(WfRay)));
 	BM_HIP(hipMalloc(&d_next_, static_cast<size_t>(queue_size_) * sizeof(WfRay)));
 	BM_HIP(hipMalloc(&d_shadow_, static_cast<size_t>(queue_size_) * sizeof(WfShadow)));
@@ -94,7 +94,7 @@ int Wavefront::frame(const bm_camera* cam, const bm_frame_params* fp, float* acc
 
 int Wavefront::stats(uint32_t* out6) {
 	if (!out6) { set_error("null argument"); return BM_EINVAL; }
-	BM_HIP(hipSetDevice(scene_->device()));
+	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipDeviceSynchronize());
 	WfState st;
 	BM_HIP(hipMemcpy(&st, d_state_, sizeof st, hipMemcpyDeviceToHost));
@@ -105,7 +105,7 @@ int Wavefront::stats(uint32_t* out6) {
 
 int Wavefront::read_queue(int which, uint32_t first, uint32_t count, void* host_out) {
 	if (!host_out || which < 0 || which > 1 || first > queue_size_ || count > queue_size_ - first) { set_error("bad argument"); return BM_EINVAL; }
-	BM_HIP(hipSetDevice(scene_->device()));
+	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipDeviceSynchronize());
 	if (which == 0) BM_HIP(hipMemcpy(host_out, d_work_ + first, static_cast<size_t>(count) * sizeof(WfRay), hipMemcpyDeviceToHost));
 	else BM_HIP(hipMemcpy(host_out, d_shadow_ + first, static_cast<size_t>(count) * sizeof(WfShadow), hipMemcpyDeviceToHost));
@@ -114,7 +114,7 @@ int Wavefront::read_queue(int which, uint32_t first, uint32_t count, void* host_
 
 int Wavefront::counters_read(int which, bm_counters* out) {
 	if (!out || which < 0 || which > 2) { set_error("bad argument"); return BM_EINVAL; }
-	BM_HIP(hipSetDevice(scene_->device()));
+	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipDeviceSynchronize());
 	DeviceCounters c[2];
 	BM_HIP(hipMemcpy(c, d_counters_, sizeof c, hipMemcpyDeviceToHost));
@@ -127,7 +127,7 @@ int Wavefront::counters_read(int which, bm_counters* out) {
 
 int Wavefront::sched_stats_read(int which, unsigned long long* out6) {
 	if (!out6 || which < 0 || which > 1) { set_error("bad argument"); return BM_EINVAL; }
-	BM_HIP(hipSetDevice(scene_->device()));
+	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipDeviceSynchronize());
 	DeviceCounters c;
 	BM_HIP(hipMemcpy(&c, d_counters_ + which, sizeof c, hipMemcpyDeviceToHost));
@@ -136,7 +136,7 @@ int Wavefront::sched_stats_read(int which, unsigned long long* out6) {
 }
 
 int Wavefront::counters_reset() {
-	BM_HIP(hipSetDevice(scene_->device()));
+	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipDeviceSynchronize());
 	BM_HIP(hipMemset(d_counters_, 0, 2 * sizeof(DeviceCounters)));
 	return 0;
@@ -145,7 +145,7 @@ int Wavefront::counters_reset() {
 int Wavefront::times(float* ms5) {
 	if (!ms5) { set_error("null argument"); return BM_EINVAL; }
 	if (!timed_) { set_error("no frame rendered yet"); return BM_ESTATE; }
-	BM_HIP(hipSetDevice(scene_->device()));
+	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipEventSynchronize(ev_[4]));
 	BM_HIP(hipEventElapsedTime(&ms5[0], ev_[0], ev_[4]));
 	for (int k = 0; k < 4; ++k) BM_HIP(hipEventElapsedTime(&ms5[1 + k], ev_[k], ev_[k + 1]));

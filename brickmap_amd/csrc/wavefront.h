@@ -10,7 +10,8 @@ namespace bm {
 
 class Wavefront {
 public:
-	Wavefront(Scene* scene, uint32_t queue_size) : scene_(scene), queue_size_(queue_size) {}
+	// the scene must outlive every frame() call; destruction itself only needs the device id
+	Wavefront(Scene* scene, uint32_t queue_size) : scene_(scene), device_(scene->device()), queue_size_(queue_size) {}
 	~Wavefront();
 	int init();
 	int reset(); // the reset_buffer branch of launch_kernels (:397-403): primary_ray_cnt = 0; the caller zeroes the frame buffer
@@ -24,6 +25,7 @@ public:
 
 private:
 	Scene* scene_;
+	int device_;
 	uint32_t queue_size_;
 	uint32_t frame_ = 1; // kernel.cu:369
 	bool reset_pending_ = false;

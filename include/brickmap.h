@@ -183,6 +183,7 @@ BM_API int bm_sched_stats_read(bm_scene* scene, bm_sched_stats* out);
  * the object's own counter (starts at 1).  Survivors and shadow rays are compacted in slot order, i.e. the
  * order a sequential run of the reference produces.  Single GPU: the queue schedule does not shard. */
 typedef struct bm_wavefront bm_wavefront;
+/* the scene must stay alive while frames are issued on the wavefront object (destroying either first is safe) */
 BM_API int bm_wavefront_create(bm_scene* scene, uint32_t queue_size, bm_wavefront** out);
 BM_API void bm_wavefront_destroy(bm_wavefront* wf);
 /* the reset_buffer branch of launch_kernels (:397-403): drop the paths in flight; the caller zeroes accum_dev */
