@@ -179,3 +179,26 @@ def test_cpp_headless_example_wavefront_schedule(bm, torch_cuda, tmp_path):
     assert data.startswith(head) and len(data) == len(head) + 160 * 96 * 3
     px = np.frombuffer(data[len(head):], np.uint8)
     assert px.max() > 0 and len(np.unique(px)) > 16
+
+
+def test_wavefront_full_size_config2_queues_match_oracle(bm, orc, torch_cuda):
+    """BASELINE config 2 scale (1080p, the reference's 2 Mi-slot queue, 1024^3 world): three consecutive launch_kernels
+    calls; every survivor and shadow record (~1.7 M each per call) is compared with oracle mode A."""
+    torch = torch_cuda
+    G, W, H, Q = 1024, 1920, 1080, 2 * 1048576
+    scene = bm.Scene(G, G, device=0).generate()
+    scene.preload_all()
+    w = orc.World(G, G, threads=os.cpu_count() or 1)
+    w.reset_device(True)
+    wf, owf = bm.Wavefront(scene, Q), orc.Wavefront(queue_size=Q, max_bounces=3)
+    p = bm.FrameParams(W, H, max_bounces=3)
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    oacc = np.zeros((H, W, 4), np.float32)
+    cam = bm.Camera(position=(G / 2, G / 8, 0.8 * G), horizontal_angle=0.8, vertical_angle=-0.5).update()
+    ocam = orc.make_camera(cam.position, cam.direction)
+    for _ in range(3):
+        wf.frame(cam, p, acc)
+        ost = owf.frame(w, ocam, W, H, oacc)
+        compare_frame(wf, owf, wf.stats(), ost)
+    assert_radiance(acc.cpu().numpy(), oacc)
+    wf.close(); scene.close()
