@@ -327,6 +327,18 @@ def test_sharded_equals_unsharded_and_accumulation(bm, orc, torch_cuda, scene256
     assert np.array_equal(acc.cpu().numpy(), full)
 
 
+@pytest.mark.parametrize("W,H,spp,mb", [(1, 1, 1, 3), (3, 5, 3, 0), (17, 1, 2, 7), (130, 33, 1, 2)])
+def test_edge_frame_shapes(W, H, spp, mb, bm, orc, torch_cuda, scene256, world256):
+    """Frames smaller than a chunk / a wave, ragged against the 4x4 chunks and 16x16 tiles, no bounces, long paths; spp = 0."""
+    cam, ocam = cameras(bm, orc, 256)
+    acc, dbg = gpu_render(bm, torch_cuda, scene256, cam, bm.FrameParams(W, H, spp=spp, max_bounces=mb))
+    oacc, odbg, _, _ = world256.render(ocam, orc.make_frame(W, H, spp=spp, max_bounces=mb))
+    assert np.array_equal(dbg, odbg)
+    assert_radiance(acc, oacc)
+    none, _ = gpu_render(bm, torch_cuda, scene256, cam, bm.FrameParams(W, H, spp=0, max_bounces=mb), want_dbg=False)
+    assert not none.any()  # no samples: the accumulation buffer is untouched
+
+
 def test_sample_sharded_frames_sum_to_the_single_render(bm, orc, torch_cuda, scene256):
     """The throughput decomposition bench.py uses at N > 1: rank r renders the FULL frame with samples
     [r*spp, (r+1)*spp); the sum of the N frames is the N*spp render up to floating-point association."""
