@@ -29,6 +29,14 @@ namespace bm {
 #ifndef BM_WF_QUORUM_DIV
 #define BM_WF_QUORUM_DIV 4
 #endif
+#ifndef BM_WF_WG
+#define BM_WF_WG 1 // 1: workgroup-balanced kernel (wf_trace_wg), 0: wave-private rays (wf_trace)
+#endif
+#if BM_WF_WG
+#define BM_WF_TRACE wf_trace_wg
+#else
+#define BM_WF_TRACE wf_trace
+#endif
 #ifndef BM_WF_STEPS
 #define BM_WF_STEPS 8
 #endif
@@ -201,6 +209,184 @@ __global__ __launch_bounds__(256, DBG ? 4 : 6) void wf_trace(const DeviceScene s
 	}
 }
 
+// ---- workgroup-balanced variant of wf_trace
+// In wf_trace a wave owns its 64 rays, so a phase runs with whatever fraction of them wants it (~53 % of the lanes in
+// a move round of extend, ~36 % in a candidate round).  Here the four waves of a workgroup pool their 256 rays: once
+// per round every live ray goes through LDS, stably partitioned by what it needs next (brick-grid moves first, then
+// candidates, empty slots last), and is picked up by thread `slot`.  Waves thereby become homogeneous -- a wave of
+// moving rays runs moves with all its lanes, the candidates sit together in another wave, the empty lanes in the last
+// wave refill from the queue -- at the price of 2 x 22 LDS transfers per ray and round and two workgroup barriers.
+// What a ray computes is unchanged (same device functions, same operands, results written per queue slot).
+#ifndef BM_WG_STEPS
+#define BM_WG_STEPS 12 // brick-grid moves per round
+#endif
+#ifndef BM_WG_PERIOD
+#define BM_WG_PERIOD 4 // phases a wave runs between two redistributions (1: 1.08 ms, 2: 1.02, 3-4: 1.01, 6: 1.03 per config-2 frame)
+#endif
+#ifndef BM_WG_GRAB
+#define BM_WG_GRAB 256 // queue slots a workgroup reserves per ticket atomic
+#endif
+constexpr int kPoolFields = 22;
+
+template <bool CONNECT, bool DBG>
+__global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScene sc, const FrameConstants* __restrict__ fcp, WfState* __restrict__ st,
+															   WfRay* __restrict__ work, const WfShadow* __restrict__ shadow, float4* __restrict__ accum,
+															   DeviceCounters* __restrict__ counters, uint32_t queue_size) {
+	const FrameConstants& fc = *fcp;
+	__shared__ unsigned long long lds_brick[8 * 256];
+	__shared__ uint32_t pool[kPoolFields][256];
+	__shared__ uint32_t wave_cnt[2][4]; // rays that want moves / candidate resolution, per wave
+	__shared__ uint32_t s_base, s_take, s_more;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t total = CONNECT ? st->shadow_ray_cnt : queue_size;
+	uint32_t* ticket = CONNECT ? st->connect_ticket : st->extend_ticket;
+
+	RayState r;
+	r.hit = false;
+	r.n = mk(0.f, 0.f, 0.f);
+	r.fine = 0ull;
+	r.block_base = 0u;
+	Tally tally;
+	HitInfo info;
+	int state = ST_NEED;
+	bool ended = false; // the lane holds a ray that has ended and whose result is not written yet
+	uint32_t idx = 0;
+	uint32_t cur = 0, end = 0; // thread 0: the workgroup's private slot range
+	bool more = true;          // thread 0: the queue may hold more slots
+	uint32_t runsA = 0, lanesA = 0, runsB = 0, lanesB = 0, runsR = 0, lanesR = 0;
+	long long rounds_left = (static_cast<long long>(total) + 256) * (2ll * sc.cells + sc.cells_height + 64); // hang guard only
+
+	for (;;) {
+		// ---- retire
+		if (ended) {
+			ended = false;
+			if (CONNECT) {
+				if (DBG) tally.shadow_rays++;
+				if (!r.hit) {
+					const float* s = reinterpret_cast<const float*>(shadow + idx);
+					atomic_add_rgb(accum + __float_as_uint(s[9]), mk(s[6], s[7], s[8]));
+				}
+			} else {
+				if (DBG) tally.extend_rays++;
+				float* rec = reinterpret_cast<float*>(work + idx);
+				rec[9] = r.n.x; rec[10] = r.n.y; rec[11] = r.n.z;
+				rec[12] = r.hit ? r.distance : kVeryFar;
+			}
+		}
+		// ---- stable partition of the workgroup's live rays: moving, then candidates; slot = position in that order
+		const bool isO = state == ST_OUTER, isC = state == ST_CAND;
+		const unsigned long long bO = __ballot(isO), bC = __ballot(isC);
+		if (lane == 0) { wave_cnt[0][wave] = static_cast<uint32_t>(__popcll(bO)); wave_cnt[1][wave] = static_cast<uint32_t>(__popcll(bC)); }
+		__syncthreads();
+		uint32_t nO = 0, nC = 0, preO = 0, preC = 0;
+		for (int w = 0; w < 4; ++w) {
+			const uint32_t o = wave_cnt[0][w], c = wave_cnt[1][w];
+			if (w < wave) { preO += o; preC += c; }
+			nO += o; nC += c;
+		}
+		const uint32_t live = nO + nC;
+		const unsigned long long below = (1ull << lane) - 1ull;
+		if (isO || isC) {
+			const uint32_t dest = isO ? preO + static_cast<uint32_t>(__popcll(bO & below)) : nO + preC + static_cast<uint32_t>(__popcll(bC & below));
+			pool[0][dest] = __float_as_uint(r.o.x); pool[1][dest] = __float_as_uint(r.o.y); pool[2][dest] = __float_as_uint(r.o.z);
+			pool[3][dest] = __float_as_uint(r.d.x); pool[4][dest] = __float_as_uint(r.d.y); pool[5][dest] = __float_as_uint(r.d.z);
+			pool[6][dest] = __float_as_uint(r.tx); pool[7][dest] = __float_as_uint(r.ty); pool[8][dest] = __float_as_uint(r.tz);
+			pool[9][dest] = __float_as_uint(r.dx); pool[10][dest] = __float_as_uint(r.dy); pool[11][dest] = __float_as_uint(r.dz);
+			pool[12][dest] = r.p; pool[13][dest] = static_cast<uint32_t>(r.sx); pool[14][dest] = static_cast<uint32_t>(r.stepy);
+			pool[15][dest] = static_cast<uint32_t>(r.stepz); pool[16][dest] = __float_as_uint(r.tminn);
+			pool[17][dest] = __float_as_uint(r.n.x); pool[18][dest] = __float_as_uint(r.n.y); pool[19][dest] = __float_as_uint(r.n.z);
+			pool[20][dest] = static_cast<uint32_t>(r.last_step); pool[21][dest] = idx;
+		}
+		if (tid == 0) { // hand out queue slots to the empty lanes (threads live .. 255) from the workgroup's private range
+			if (cur == end && more) {
+				const uint32_t b = atomicAdd(ticket, static_cast<uint32_t>(BM_WG_GRAB));
+				if (b >= total) more = false;
+				else { cur = b; end = total - b < static_cast<uint32_t>(BM_WG_GRAB) ? total : b + static_cast<uint32_t>(BM_WG_GRAB); }
+			}
+			const uint32_t avail = end - cur, empty = 256u - live;
+			const uint32_t take = empty < avail ? empty : avail;
+			s_base = cur; s_take = take;
+			cur += take;
+			s_more = (more || cur < end) ? 1u : 0u;
+		}
+		__syncthreads();
+		const uint32_t take = s_take, base = s_base;
+		if (live == 0 && take == 0 && s_more == 0u) break; // (uniform over the workgroup)
+		if (--rounds_left < 0) break;
+		if (static_cast<uint32_t>(tid) < live) {
+			r.o = mk(__uint_as_float(pool[0][tid]), __uint_as_float(pool[1][tid]), __uint_as_float(pool[2][tid]));
+			r.d = mk(__uint_as_float(pool[3][tid]), __uint_as_float(pool[4][tid]), __uint_as_float(pool[5][tid]));
+			r.tx = __uint_as_float(pool[6][tid]); r.ty = __uint_as_float(pool[7][tid]); r.tz = __uint_as_float(pool[8][tid]);
+			r.dx = __uint_as_float(pool[9][tid]); r.dy = __uint_as_float(pool[10][tid]); r.dz = __uint_as_float(pool[11][tid]);
+			r.p = pool[12][tid]; r.sx = static_cast<int>(pool[13][tid]); r.stepy = static_cast<int>(pool[14][tid]);
+			r.stepz = static_cast<int>(pool[15][tid]); r.tminn = __uint_as_float(pool[16][tid]);
+			r.n = mk(__uint_as_float(pool[17][tid]), __uint_as_float(pool[18][tid]), __uint_as_float(pool[19][tid]));
+			r.last_step = static_cast<int>(pool[20][tid]); idx = pool[21][tid];
+			r.hit = false;
+			state = static_cast<uint32_t>(tid) < nO ? ST_OUTER : ST_CAND;
+		} else {
+			state = ST_NEED;
+			// ---- refill: the empty lanes are the last threads of the workgroup
+			const uint32_t k = static_cast<uint32_t>(tid) - live;
+			if (k < take) {
+				idx = base + k;
+				f3 o, d;
+				if (CONNECT) {
+					const float2* s = reinterpret_cast<const float2*>(shadow + idx);
+					const float2 u = s[0], v = s[1], w2 = s[2];
+					o = mk(u.x, u.y, v.x);
+					d = mk(v.y, w2.x, w2.y);
+					r.n = mk(0.f, 0.f, 0.f); // connect passes a zeroed normal (kernel.cu:338)
+				} else {
+					const float4* q = reinterpret_cast<const float4*>(work + idx);
+					const float4 u = q[0], v = q[1], w2 = q[2];
+					o = mk(u.x, u.y, u.z);
+					d = mk(u.w, v.x, v.y);
+					r.n = mk(w2.y, w2.z, w2.w);
+				}
+				state = ray_setup<DBG>(sc, o, d, r, tally);
+				ended = state == ST_NEED; // missed the world box
+			}
+		}
+		if (DBG && take > 0 && tid == 0) { runsR++; lanesR += take; }
+		// ---- BM_WG_PERIOD phases per wave and redistribution: each time whichever the majority of its live lanes wants
+#pragma unroll 1
+		for (int ph = 0; ph < BM_WG_PERIOD; ++ph) {
+			const int nAw = __popcll(__ballot(state == ST_OUTER)), nBw = __popcll(__ballot(state == ST_CAND));
+			if (nBw > 0 && nBw >= nAw) {
+				if (DBG && lane == 0) { runsB++; lanesB += nBw; }
+				if (state == ST_CAND) {
+					load_block(sc, r); // the block record (mask, arena base) is not carried through the pool
+					state = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick);
+					if (state == ST_NEED) ended = true;
+				}
+			} else if (nAw > 0) {
+				const bool walking = state == ST_OUTER;
+#pragma unroll 1
+				for (int k = 0; k < BM_WG_STEPS; ++k) {
+					if (DBG) { const int n = __popcll(__ballot(state == ST_OUTER)); if (lane == 0) { runsA++; lanesA += n; } }
+					if (state == ST_OUTER) state = outer_step<DBG>(sc, r, tally);
+				}
+				if (walking && state == ST_NEED) ended = true; // left the grid
+			}
+		}
+	}
+
+	if (DBG && counters) {
+		unsigned long long v[8] = {tally.index_loads, tally.brick_tests, tally.byte_tests, tally.voxel_steps,
+								   tally.extend_rays, tally.shadow_rays, tally.requests, tally.paths};
+		for (int k = 0; k < 8; ++k) {
+			unsigned long long t = v[k];
+			for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+			if (lane == 0 && t) atomicAdd(&counters->v[k], t);
+		}
+		if (lane == 0) {
+			const unsigned long long st8[8] = {runsA, lanesA, runsB, lanesB, runsR, lanesR, 0ull, 0ull};
+			for (int k = 0; k < 8; ++k) atomicAdd(&counters->sched[k], st8[k]);
+		}
+	}
+}
+
 // shade (kernel.cu:242-325), two passes over the work queue with a prefix sum in between.
 //   EMIT = false: count the survivors and shadow rays of each 256-slot block
 //   EMIT = true : redo the (cheap, coherent) shading and write every output at offset[block] + rank in block
@@ -322,10 +508,10 @@ __global__ __launch_bounds__(1024) void wf_scan(uint2* __restrict__ block_counts
 int wavefront_blocks_per_cu(bool connect, bool instrumented) {
 	int n = 0;
 	hipError_t e;
-	if (connect) e = instrumented ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace<true, true>, 256, 0)
-								  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace<true, false>, 256, 0);
-	else e = instrumented ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace<false, true>, 256, 0)
-						  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wf_trace<false, false>, 256, 0);
+	if (connect) e = instrumented ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, BM_WF_TRACE<true, true>, 256, 0)
+								  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, BM_WF_TRACE<true, false>, 256, 0);
+	else e = instrumented ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, BM_WF_TRACE<false, true>, 256, 0)
+						  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, BM_WF_TRACE<false, false>, 256, 0);
 	return e == hipSuccess && n > 0 ? n : 1;
 }
 
@@ -342,11 +528,11 @@ void launch_wf_trace(bool connect, const DeviceScene& sc, const FrameConstants* 
 	const dim3 grid(static_cast<unsigned>(blocks)), block(256);
 	float4* acc = reinterpret_cast<float4*>(accum);
 	if (connect) {
-		if (counters) hipLaunchKernelGGL((wf_trace<true, true>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size);
-		else hipLaunchKernelGGL((wf_trace<true, false>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size);
+		if (counters) hipLaunchKernelGGL((BM_WF_TRACE<true, true>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size);
+		else hipLaunchKernelGGL((BM_WF_TRACE<true, false>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size);
 	} else {
-		if (counters) hipLaunchKernelGGL((wf_trace<false, true>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size);
-		else hipLaunchKernelGGL((wf_trace<false, false>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size);
+		if (counters) hipLaunchKernelGGL((BM_WF_TRACE<false, true>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size);
+		else hipLaunchKernelGGL((BM_WF_TRACE<false, false>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size);
 	}
 }
 
