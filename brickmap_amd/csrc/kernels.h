@@ -19,7 +19,7 @@ void launch_debug_sky(const FrameConstants& fc, int n, const float* v, float* su
 int wavefront_blocks_per_cu(bool connect, bool instrumented);
 void launch_wf_primary(WfState* st, WfRay* work, const FrameConstants* fc_dev, uint32_t queue_size, uint32_t pixels, hipStream_t stream);
 void launch_wf_trace(bool connect, const DeviceScene& sc, const FrameConstants* fc_dev, WfState* st, WfRay* work, const WfShadow* shadow, float* accum,
-					 DeviceCounters* counters, uint32_t queue_size, int resident_blocks, hipStream_t stream);
+					 DeviceCounters* counters, uint32_t queue_size, int resident_blocks, void* cold_scratch, hipStream_t stream);
 void launch_wf_shade(const WfRay* work, WfRay* next, WfShadow* shadow, float* accum, void* block_counts, WfState* st, const FrameConstants* fc_dev,
 					 uint32_t queue_size, hipStream_t stream);
 } // namespace bm

@@ -11,7 +11,7 @@ namespace bm {
 Wavefront::~Wavefront() {
 	if (hipSetDevice(device_) != hipSuccess) return;
 	(void)hipDeviceSynchronize();
-	(void)hipFree(d_work_); (void)hipFree(d_next_); (void)hipFree(d_shadow_); (void)hipFree(d_state_); (void)hipFree(d_block_counts_); (void)hipFree(d_counters_);
+	(void)hipFree(d_work_); (void)hipFree(d_next_); (void)hipFree(d_shadow_); (void)hipFree(d_state_); (void)hipFree(d_block_counts_); (void)hipFree(d_cold_); (void)hipFree(d_counters_);
 	(void)hipFree(d_frame_constants_);
 	if (h_frame_constants_) (void)hipHostFree(h_frame_constants_);
 	for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
@@ -25,6 +25,7 @@ int Wavefront::init() {
 	BM_HIP(hipMalloc(&d_shadow_, static_cast<size_t>(queue_size_) * sizeof(WfShadow)));
 	BM_HIP(hipMalloc(&d_state_, sizeof(WfState)));
 	BM_HIP(hipMalloc(&d_block_counts_, (static_cast<size_t>(queue_size_) / 256 + 1) * 8));
+	BM_HIP(hipMalloc(&d_cold_, static_cast<size_t>(queue_size_) * 16));
 	BM_HIP(hipMalloc(&d_frame_constants_, kConstantsRing * sizeof(FrameConstants)));
 	BM_HIP(hipHostMalloc(&h_frame_constants_, kConstantsRing * sizeof(FrameConstants), hipHostMallocDefault));
 	BM_HIP(hipMemset(d_work_, 0, static_cast<size_t>(queue_size_) * sizeof(WfRay)));
@@ -78,11 +79,11 @@ int Wavefront::frame(const bm_camera* cam, const bm_frame_params* fp, float* acc
 	BM_HIP(hipEventRecord(ev_[0], stream));
 	launch_wf_primary(d_state_, d_work_, fc_dev, queue_size_, static_cast<uint32_t>(pixels), stream);
 	BM_HIP(hipEventRecord(ev_[1], stream));
-	launch_wf_trace(false, view, fc_dev, d_state_, d_work_, d_shadow_, accum, counters_extend, queue_size_, cus * blocks_per_cu_[0][instrumented ? 1 : 0], stream);
+	launch_wf_trace(false, view, fc_dev, d_state_, d_work_, d_shadow_, accum, counters_extend, queue_size_, cus * blocks_per_cu_[0][instrumented ? 1 : 0], d_cold_, stream);
 	BM_HIP(hipEventRecord(ev_[2], stream));
 	launch_wf_shade(d_work_, d_next_, d_shadow_, accum, d_block_counts_, d_state_, fc_dev, queue_size_, stream);
 	BM_HIP(hipEventRecord(ev_[3], stream));
-	launch_wf_trace(true, view, fc_dev, d_state_, d_work_, d_shadow_, accum, counters_connect, queue_size_, cus * blocks_per_cu_[1][instrumented ? 1 : 0], stream);
+	launch_wf_trace(true, view, fc_dev, d_state_, d_work_, d_shadow_, accum, counters_connect, queue_size_, cus * blocks_per_cu_[1][instrumented ? 1 : 0], d_cold_, stream);
 	BM_HIP(hipEventRecord(ev_[4], stream));
 	BM_HIP(hipGetLastError());
 	timed_ = true;

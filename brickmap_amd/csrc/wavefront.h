@@ -34,6 +34,7 @@ private:
 	WfShadow* d_shadow_ = nullptr;
 	WfState* d_state_ = nullptr;
 	void* d_block_counts_ = nullptr;
+	void* d_cold_ = nullptr; // 16 bytes per queue slot: ray state that only candidate resolution reads (wavefront.hip)
 	DeviceCounters* d_counters_ = nullptr; // [0] extend, [1] connect (BM_FLAG_COUNTERS frames)
 	static constexpr int kConstantsRing = 64;
 	FrameConstants* d_frame_constants_ = nullptr;

@@ -90,7 +90,7 @@ __global__ void wf_globals(WfState* st, uint32_t queue_size, uint32_t pixels) {
 template <bool CONNECT, bool DBG>
 __global__ __launch_bounds__(256, DBG ? 4 : 6) void wf_trace(const DeviceScene sc, const FrameConstants* __restrict__ fcp, WfState* __restrict__ st,
 											   WfRay* __restrict__ work, const WfShadow* __restrict__ shadow, float4* __restrict__ accum,
-											   DeviceCounters* __restrict__ counters, uint32_t queue_size) {
+											   DeviceCounters* __restrict__ counters, uint32_t queue_size, float4* __restrict__ /*cold: wf_trace_wg only*/) {
 	const FrameConstants& fc = *fcp;
 	__shared__ unsigned long long lds_brick[8 * 256];
 	const int lane = threadIdx.x & 63;
@@ -215,23 +215,28 @@ __global__ __launch_bounds__(256, DBG ? 4 : 6) void wf_trace(const DeviceScene s
 // per round every live ray goes through LDS, stably partitioned by what it needs next (brick-grid moves first, then
 // candidates, empty slots last), and is picked up by thread `slot`.  Waves thereby become homogeneous -- a wave of
 // moving rays runs moves with all its lanes, the candidates sit together in another wave, the empty lanes in the last
-// wave refill from the queue -- at the price of 2 x 22 LDS transfers per ray and round and two workgroup barriers.
+// wave refill from the queue -- at the price of 2 x 15 LDS transfers per ray and redistribution and two workgroup
+// barriers.  Only what the brick-grid move needs travels through LDS; what only candidate resolution reads (origin in
+// brick units, entry distance; the direction is in the queue record) is parked in a per-slot global scratch record.
 // What a ray computes is unchanged (same device functions, same operands, results written per queue slot).
 #ifndef BM_WG_STEPS
-#define BM_WG_STEPS 12 // brick-grid moves per round
+#define BM_WG_STEPS 10 // brick-grid moves per phase
 #endif
 #ifndef BM_WG_PERIOD
 #define BM_WG_PERIOD 4 // phases a wave runs between two redistributions (1: 1.08 ms, 2: 1.02, 3-4: 1.01, 6: 1.03 per config-2 frame)
 #endif
+#ifndef BM_WG_CAND_MIN
+#define BM_WG_CAND_MIN 8 // a wave resolves candidates when this many lanes hold one (or when they outnumber its moving lanes)
+#endif
 #ifndef BM_WG_GRAB
 #define BM_WG_GRAB 256 // queue slots a workgroup reserves per ticket atomic
 #endif
-constexpr int kPoolFields = 22;
+constexpr int kPoolFields = 15;
 
 template <bool CONNECT, bool DBG>
 __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScene sc, const FrameConstants* __restrict__ fcp, WfState* __restrict__ st,
 															   WfRay* __restrict__ work, const WfShadow* __restrict__ shadow, float4* __restrict__ accum,
-															   DeviceCounters* __restrict__ counters, uint32_t queue_size) {
+															   DeviceCounters* __restrict__ counters, uint32_t queue_size, float4* __restrict__ cold) {
 	const FrameConstants& fc = *fcp;
 	__shared__ unsigned long long lds_brick[8 * 256];
 	__shared__ uint32_t pool[kPoolFields][256];
@@ -288,14 +293,12 @@ __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScen
 		const unsigned long long below = (1ull << lane) - 1ull;
 		if (isO || isC) {
 			const uint32_t dest = isO ? preO + static_cast<uint32_t>(__popcll(bO & below)) : nO + preC + static_cast<uint32_t>(__popcll(bC & below));
-			pool[0][dest] = __float_as_uint(r.o.x); pool[1][dest] = __float_as_uint(r.o.y); pool[2][dest] = __float_as_uint(r.o.z);
-			pool[3][dest] = __float_as_uint(r.d.x); pool[4][dest] = __float_as_uint(r.d.y); pool[5][dest] = __float_as_uint(r.d.z);
-			pool[6][dest] = __float_as_uint(r.tx); pool[7][dest] = __float_as_uint(r.ty); pool[8][dest] = __float_as_uint(r.tz);
-			pool[9][dest] = __float_as_uint(r.dx); pool[10][dest] = __float_as_uint(r.dy); pool[11][dest] = __float_as_uint(r.dz);
-			pool[12][dest] = r.p; pool[13][dest] = static_cast<uint32_t>(r.sx); pool[14][dest] = static_cast<uint32_t>(r.stepy);
-			pool[15][dest] = static_cast<uint32_t>(r.stepz); pool[16][dest] = __float_as_uint(r.tminn);
-			pool[17][dest] = __float_as_uint(r.n.x); pool[18][dest] = __float_as_uint(r.n.y); pool[19][dest] = __float_as_uint(r.n.z);
-			pool[20][dest] = static_cast<uint32_t>(r.last_step); pool[21][dest] = idx;
+			pool[0][dest] = __float_as_uint(r.tx); pool[1][dest] = __float_as_uint(r.ty); pool[2][dest] = __float_as_uint(r.tz);
+			pool[3][dest] = __float_as_uint(r.dx); pool[4][dest] = __float_as_uint(r.dy); pool[5][dest] = __float_as_uint(r.dz);
+			pool[6][dest] = r.p; pool[7][dest] = static_cast<uint32_t>(r.sx); pool[8][dest] = static_cast<uint32_t>(r.stepy);
+			pool[9][dest] = static_cast<uint32_t>(r.stepz);
+			pool[10][dest] = __float_as_uint(r.n.x); pool[11][dest] = __float_as_uint(r.n.y); pool[12][dest] = __float_as_uint(r.n.z);
+			pool[13][dest] = static_cast<uint32_t>(r.last_step); pool[14][dest] = idx;
 		}
 		if (tid == 0) { // hand out queue slots to the empty lanes (threads live .. 255) from the workgroup's private range
 			if (cur == end && more) {
@@ -314,14 +317,12 @@ __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScen
 		if (live == 0 && take == 0 && s_more == 0u) break; // (uniform over the workgroup)
 		if (--rounds_left < 0) break;
 		if (static_cast<uint32_t>(tid) < live) {
-			r.o = mk(__uint_as_float(pool[0][tid]), __uint_as_float(pool[1][tid]), __uint_as_float(pool[2][tid]));
-			r.d = mk(__uint_as_float(pool[3][tid]), __uint_as_float(pool[4][tid]), __uint_as_float(pool[5][tid]));
-			r.tx = __uint_as_float(pool[6][tid]); r.ty = __uint_as_float(pool[7][tid]); r.tz = __uint_as_float(pool[8][tid]);
-			r.dx = __uint_as_float(pool[9][tid]); r.dy = __uint_as_float(pool[10][tid]); r.dz = __uint_as_float(pool[11][tid]);
-			r.p = pool[12][tid]; r.sx = static_cast<int>(pool[13][tid]); r.stepy = static_cast<int>(pool[14][tid]);
-			r.stepz = static_cast<int>(pool[15][tid]); r.tminn = __uint_as_float(pool[16][tid]);
-			r.n = mk(__uint_as_float(pool[17][tid]), __uint_as_float(pool[18][tid]), __uint_as_float(pool[19][tid]));
-			r.last_step = static_cast<int>(pool[20][tid]); idx = pool[21][tid];
+			r.tx = __uint_as_float(pool[0][tid]); r.ty = __uint_as_float(pool[1][tid]); r.tz = __uint_as_float(pool[2][tid]);
+			r.dx = __uint_as_float(pool[3][tid]); r.dy = __uint_as_float(pool[4][tid]); r.dz = __uint_as_float(pool[5][tid]);
+			r.p = pool[6][tid]; r.sx = static_cast<int>(pool[7][tid]); r.stepy = static_cast<int>(pool[8][tid]);
+			r.stepz = static_cast<int>(pool[9][tid]);
+			r.n = mk(__uint_as_float(pool[10][tid]), __uint_as_float(pool[11][tid]), __uint_as_float(pool[12][tid]));
+			r.last_step = static_cast<int>(pool[13][tid]); idx = pool[14][tid];
 			r.hit = false;
 			state = static_cast<uint32_t>(tid) < nO ? ST_OUTER : ST_CAND;
 		} else {
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScen
 				}
 				state = ray_setup<DBG>(sc, o, d, r, tally);
 				ended = state == ST_NEED; // missed the world box
+				if (!ended) cold[idx] = make_float4(r.o.x, r.o.y, r.o.z, r.tminn); // read back by candidate resolution
 			}
 		}
 		if (DBG && take > 0 && tid == 0) { runsR++; lanesR += take; }
@@ -353,10 +355,17 @@ __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScen
 #pragma unroll 1
 		for (int ph = 0; ph < BM_WG_PERIOD; ++ph) {
 			const int nAw = __popcll(__ballot(state == ST_OUTER)), nBw = __popcll(__ballot(state == ST_CAND));
-			if (nBw > 0 && nBw >= nAw) {
+			if (nBw > 0 && (nBw >= BM_WG_CAND_MIN || nBw >= nAw)) {
 				if (DBG && lane == 0) { runsB++; lanesB += nBw; }
 				if (state == ST_CAND) {
-					load_block(sc, r); // the block record (mask, arena base) is not carried through the pool
+					// what only this phase reads is not carried through the pool: the block record (mask, arena base),
+					// the ray's origin in brick units and entry distance (scratch record), its direction (queue record)
+					load_block(sc, r);
+					const float4 c = cold[idx];
+					const float* q = CONNECT ? reinterpret_cast<const float*>(shadow + idx) : reinterpret_cast<const float*>(work + idx);
+					r.o = mk(c.x, c.y, c.z);
+					r.tminn = c.w;
+					r.d = mk(q[3], q[4], q[5]);
 					state = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick);
 					if (state == ST_NEED) ended = true;
 				}
@@ -521,18 +530,19 @@ void launch_wf_primary(WfState* st, WfRay* work, const FrameConstants* fc_dev, u
 }
 
 void launch_wf_trace(bool connect, const DeviceScene& sc, const FrameConstants* fc_dev, WfState* st, WfRay* work, const WfShadow* shadow, float* accum,
-					 DeviceCounters* counters, uint32_t queue_size, int resident_blocks, hipStream_t stream) {
+					 DeviceCounters* counters, uint32_t queue_size, int resident_blocks, void* cold_scratch, hipStream_t stream) {
 	long long blocks = (static_cast<long long>(queue_size) + BM_WF_GRAB * 4 - 1) / (BM_WF_GRAB * 4); // never more waves than slot ranges
 	if (blocks > resident_blocks) blocks = resident_blocks;
 	if (blocks < 1) blocks = 1;
 	const dim3 grid(static_cast<unsigned>(blocks)), block(256);
 	float4* acc = reinterpret_cast<float4*>(accum);
+	float4* cold = reinterpret_cast<float4*>(cold_scratch);
 	if (connect) {
-		if (counters) hipLaunchKernelGGL((BM_WF_TRACE<true, true>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size);
-		else hipLaunchKernelGGL((BM_WF_TRACE<true, false>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size);
+		if (counters) hipLaunchKernelGGL((BM_WF_TRACE<true, true>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size, cold);
+		else hipLaunchKernelGGL((BM_WF_TRACE<true, false>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size, cold);
 	} else {
-		if (counters) hipLaunchKernelGGL((BM_WF_TRACE<false, true>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size);
-		else hipLaunchKernelGGL((BM_WF_TRACE<false, false>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size);
+		if (counters) hipLaunchKernelGGL((BM_WF_TRACE<false, true>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size, cold);
+		else hipLaunchKernelGGL((BM_WF_TRACE<false, false>), grid, block, 0, stream, sc, fc_dev, st, work, shadow, acc, counters, queue_size, cold);
 	}
 }
 
