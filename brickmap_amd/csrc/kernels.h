@@ -9,11 +9,6 @@ constexpr size_t kWorkCounterBytes = 64 * 32 * sizeof(uint32_t); // up to 64 chu
 int trace_blocks_per_cu(bool instrumented);
 void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameConstants* fc_dev, float* accum, uint32_t* dbg, DeviceCounters* counters,
 				  uint32_t* work_counter, bool instrumented, int resident_blocks, hipStream_t stream);
-// workgroup-balanced variant of the fused kernel (trace_wg.hip)
-size_t trace_wg_scratch_bytes(int resident_blocks);
-int trace_wg_blocks_per_cu(bool instrumented);
-void launch_trace_wg(const DeviceScene& sc, const FrameConstants& fc, const FrameConstants* fc_dev, float* accum, uint32_t* dbg, DeviceCounters* counters,
-					 uint32_t* work_counter, bool instrumented, int resident_blocks, void* scratch, hipStream_t stream);
 void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const uint32_t* indices_queue, uint32_t* arena, uint32_t count,
 				   hipStream_t stream);
 void launch_resolve(const float* accum, float* out, long long n, hipStream_t stream);

@@ -127,7 +127,6 @@ Scene::~Scene() {
 	if (d_indices_queue_) hipFree(d_indices_queue_);
 	if (d_counters_) hipFree(d_counters_);
 	if (d_work_counter_) hipFree(d_work_counter_);
-	if (d_wg_scratch_) hipFree(d_wg_scratch_);
 	if (d_frame_constants_) hipFree(d_frame_constants_);
 	if (h_frame_constants_) hipHostFree(h_frame_constants_);
 	for (int i = 0; i < kTimingRing; ++i) {
@@ -173,13 +172,7 @@ int Scene::init(int grid_size, int grid_height) {
 	compute_units_ = prop.multiProcessorCount; // main.cpp:97 sm_cores
 	blocks_per_cu_[0] = trace_blocks_per_cu(false);
 	blocks_per_cu_[1] = trace_blocks_per_cu(true);
-	if (const char* e = std::getenv("BM_TRACE_WG")) use_wg_ = e[0] == '1';
-	if (use_wg_) {
-		wg_blocks_per_cu_[0] = trace_wg_blocks_per_cu(false);
-		wg_blocks_per_cu_[1] = trace_wg_blocks_per_cu(true);
-		const int most = std::max(wg_blocks_per_cu_[0], wg_blocks_per_cu_[1]);
-		BM_HIP(hipMalloc(&d_wg_scratch_, trace_wg_scratch_bytes(compute_units_ * most)));
-	}
+
 	return alloc_queue();
 }
 
@@ -541,12 +534,8 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 #else
 	DeviceCounters* const counters_arg = (fp->flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr;
 #endif
-	if (use_wg_)
-		launch_trace_wg(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, d_work_counter_, instrumented,
-						compute_units_ * wg_blocks_per_cu_[instrumented ? 1 : 0], d_wg_scratch_, stream);
-	else
-		launch_trace(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, d_work_counter_, instrumented,
-					 compute_units_ * blocks_per_cu_[instrumented ? 1 : 0], stream);
+	launch_trace(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, d_work_counter_, instrumented,
+				 compute_units_ * blocks_per_cu_[instrumented ? 1 : 0], stream);
 	BM_HIP(hipGetLastError());
 	BM_HIP(hipEventRecord(ev_stop_[slot], stream));
 	launches_++;

@@ -96,10 +96,6 @@ private:
 	FrameConstants* h_frame_constants_ = nullptr; // pinned source of the copies
 	uint32_t* d_work_counter_ = nullptr; // chunk counter of the persistent trace kernel, zeroed before each launch
 	int compute_units_ = 0, blocks_per_cu_[2] = {0, 0};
-	// workgroup-balanced fused kernel (trace_wg.hip): selected with BM_TRACE_WG=1 in the environment
-	bool use_wg_ = false;
-	int wg_blocks_per_cu_[2] = {0, 0};
-	void* d_wg_scratch_ = nullptr;
 	// pinned staging (Scene.cpp:30-32)
 	int* h_positions_[2] = {nullptr, nullptr};
 	uint32_t* h_bricks_ = nullptr;
