@@ -53,6 +53,13 @@ struct DeviceScene {
 	                             // walk indexes it with block coordinates that carry the packed cell's bias (load_block)
 	int bg_x, bg_xy;             // row / slice pitch in blocks
 	const uint32_t* brick_arena; // 16 words per brick
+	// octant cube field (traverse.h "cube-field walk"): 8 planes of one byte per cell of the grid plus a one-cell border,
+	// x-fastest; byte = edge of the largest empty cube with the cell as near corner along the plane's octant (bit 0 / 1 /
+	// 2 of the plane number = direction negative in x / y / z), 0 = the cell holds a brick, 255 = border (outside).
+	// Points 15 * (1 + cf_x + cf_xy) bytes BEFORE plane 0: the walk indexes it with the biased fields of the packed cell.
+	const uint8_t* cube_field;
+	int cf_x, cf_xy;    // row / slice pitch in cells
+	uint32_t cf_plane;  // bytes per plane
 	int* load_queue;             // 3 ints per entry
 	uint32_t* load_queue_count;
 	uint32_t queue_cap;
@@ -94,7 +101,7 @@ struct FrameConstants {
 struct DeviceCounters { // v: same order as bm_counters; sched: same order as bm_sched_stats
 	unsigned long long v[8];
 	unsigned long long sched[8];
-	unsigned long long cycles[8]; // s_memtime ticks per scheduler phase, summed over waves: A, B, C, D, total, 0, 0, waves
+	unsigned long long cycles[8]; // s_memtime ticks per scheduler phase, summed over waves: A, B, C, D, total; jump runs, jump lanes; waves
 };
 
 // ---- wavefront mode (wavefront.hip): the reference's queue records and device globals

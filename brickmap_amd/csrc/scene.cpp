@@ -147,6 +147,11 @@ int Scene::init(int grid_size, int grid_height) {
 		set_error("worlds larger than 8192 x 8192 x 7936 voxels are not supported");
 		return BM_EINVAL;
 	}
+	// the walk addresses the 8 planes of the octant cube field with one 32-bit offset (traverse.h field_lookup)
+	if (8ull * static_cast<uint64_t>(world.dims.cells + 2) * (world.dims.cells + 2) * (world.dims.cells_height + 2) >= (1ull << 32)) {
+		set_error("world too large: the octant cube field (8 bytes per brick cell) must stay below 4 GiB");
+		return BM_EINVAL;
+	}
 	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipStreamCreateWithFlags(&load_stream_, hipStreamNonBlocking));
 	BM_HIP(hipStreamCreateWithFlags(&kernel_stream_, hipStreamNonBlocking));
@@ -248,6 +253,8 @@ void Scene::free_device() {
 	if (d_super_info_) hipFree(d_super_info_);
 	if (d_block_grid_) hipFree(d_block_grid_);
 	if (d_arena_) hipFree(d_arena_);
+	if (d_cube_field_) hipFree(d_cube_field_);
+	d_cube_field_ = nullptr;
 	d_index_grid_ = d_arena_ = nullptr;
 	d_super_info_ = nullptr;
 	d_block_grid_ = nullptr;
@@ -298,6 +305,18 @@ int Scene::allocate_device() {
 	view_.bg_x = nbx;
 	view_.bg_xy = nbx * nbx;
 	view_.brick_arena = d_arena_;
+	{ // octant cube field: what the walk reads instead of index words while it crosses empty space
+		std::vector<uint8_t> field;
+		world.build_cube_field(field, 8);
+		BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cube_field_), field.size()));
+		BM_HIP(hipMemcpy(d_cube_field_, field.data(), field.size(), hipMemcpyHostToDevice));
+		const int cfx = d.cells + 2;
+		view_.cf_x = cfx;
+		view_.cf_xy = cfx * cfx;
+		view_.cf_plane = static_cast<uint32_t>(field.size() / 8);
+		view_.cube_field = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(d_cube_field_) - static_cast<uintptr_t>(15) * (1 + cfx + cfx * cfx));
+		cube_field_bytes_ = field.size();
+	}
 	view_.cells = d.cells;
 	view_.cells_height = d.cells_height;
 	view_.sg_xy = d.supergrid_xy;

@@ -85,6 +85,8 @@ private:
 	SuperInfo* d_super_info_ = nullptr;
 	BlockInfo* d_block_grid_ = nullptr;
 	uint32_t* d_arena_ = nullptr;
+	uint8_t* d_cube_field_ = nullptr;
+	uint64_t cube_field_bytes_ = 0;
 	// two request rings: the blocking (reference-order) mode only uses ring 0; the overlapped mode alternates them so
 	// that a frame can raise requests while the previous frame's ring is being copied out and serviced
 	int* d_load_queue_[2] = {nullptr, nullptr};

@@ -43,16 +43,37 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #define BM_WORK_COUNTERS 8
 #endif
 #ifndef BM_QUORUM_DIV
-#define BM_QUORUM_DIV 4
+#define BM_QUORUM_DIV 2
 #endif
 #ifndef BM_QUORUM_SHADE_DIV
-#define BM_QUORUM_SHADE_DIV BM_QUORUM_DIV
+#define BM_QUORUM_SHADE_DIV 4
 #endif
 #ifndef BM_QUORUM_CONN_DIV
 #define BM_QUORUM_CONN_DIV 8
 #endif
 #ifndef BM_STEPS_PER_ROUND
-#define BM_STEPS_PER_ROUND 12
+#define BM_STEPS_PER_ROUND 4
+#endif
+#ifndef BM_POLICY
+#define BM_POLICY 0
+#endif
+#ifndef BM_COST_A
+#define BM_COST_A 160
+#endif
+#ifndef BM_COST_B
+#define BM_COST_B 580
+#endif
+#ifndef BM_COST_C
+#define BM_COST_C 550
+#endif
+#ifndef BM_COST_D
+#define BM_COST_D 250
+#endif
+#ifndef BM_REFILL_MIN
+#define BM_REFILL_MIN 16
+#endif
+#ifndef BM_JUMP_RATIO
+#define BM_JUMP_RATIO 4 // a move round is a jump pass when (lanes with a cube ahead) * ratio >= (lanes near the surface)
 #endif
 // -DBM_PHASE_TIMING: profiling build in which the plain kernel also reports the scheduler statistics
 #ifdef BM_PHASE_TIMING
@@ -94,6 +115,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	f3 pn = mk(0.f, 0.f, 0.f);     // surface normal of the path (RayQueue::normal)
 	f3 scolor = mk(0.f, 0.f, 0.f); // ShadowQueue::color
 	f3 bdir = mk(0.f, 0.f, 0.f);   // next bounce direction, drawn in shade, used once the shadow ray is done
+	// the pixel's accumulator (state.h:22): read when the lane takes the pixel, updated in path order in registers, written
+	// back once when the pixel is finished -- a read-modify-write in memory per event stalls the wave for a load round trip
+	float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 
 	bool work_left = true;
 	constexpr uint32_t kCounters = BM_WORK_COUNTERS, kCounterStride = 32; // one 128-byte line per counter
@@ -102,7 +126,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	// hang guard only (NaN directions): no wave needs more scheduler rounds than this
 	long long rounds_left = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fc.spp) + 1) * (fc.max_bounces + 2) *
 							(2ll * sc.cells + sc.cells_height + 64);
-	uint32_t runsA = 0, lanesA = 0, runsB = 0, lanesB = 0, runsC = 0, lanesC = 0, runsD = 0, lanesD = 0; // wave-uniform scheduler statistics
+	uint32_t runsA = 0, lanesA = 0, runsB = 0, lanesB = 0, runsC = 0, lanesC = 0, runsD = 0, lanesD = 0, runsJ = 0, lanesJ = 0; // wave-uniform scheduler statistics
 
 	unsigned long long cycA = 0, cycB = 0, cycC = 0, cycD = 0;
 	const unsigned long long t_begin = BM_TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -111,7 +135,10 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		// ---- refill: hand pixels to idle lanes, 16 (one 4x4 chunk) at a time
 		const unsigned long long idle = __ballot(state == ST_IDLE);
 		const int nI = __popcll(idle);
-		if (work_left && nI >= 16) {
+#ifdef BM_TIME_REFILL
+		const unsigned long long t_refill = __builtin_amdgcn_s_memtime();
+#endif
+		if (work_left && nI >= BM_REFILL_MIN) {
 			// One global word serves only ~90 returning atomics per microsecond chip-wide, and a refill stalls the whole
 			// wave until its atomic returns; with thousands of waves on one counter that queue is tens of microseconds
 			// long.  The chunk sequence is therefore dealt to kCounters interleaved counters (8x8-pixel groups of four
@@ -149,6 +176,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						s = 0;
 						pstate = P_GEN;
 						state = ST_NEED;
+						acc = accum[local_pixel];
 						if (DBG) {
 							d0 = 0; d1 = 0; d2 = 0xFFFFFFFFu; d3 = 0; hseg = 2166136261u; hsh = 2166136261u; next = 0; nsh = 0;
 							loads0 = tally.index_loads;
@@ -157,7 +185,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				}
 			}
 		}
-		const int nA = __popcll(__ballot(state == ST_OUTER));
+#ifdef BM_TIME_REFILL
+		if (work_left && nI >= 16) cycD += __builtin_amdgcn_s_memtime() - t_refill; // experiment: refill time in the connect slot
+#endif
+		const int nJ = __popcll(__ballot(state == ST_JUMP));
+		const int nA = __popcll(__ballot(state == ST_OUTER)) + nJ; // lanes walking the brick grid, cell by cell or cube by cube
 		const int nB = __popcll(__ballot(state == ST_CAND));
 		const int nC = __popcll(__ballot(state == ST_NEED));
 		const int nD = __popcll(__ballot(state == ST_CONN));
@@ -172,11 +204,25 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		const int quorum = (live + BM_QUORUM_DIV - 1) / BM_QUORUM_DIV, quorum_conn = (live + BM_QUORUM_CONN_DIV - 1) / BM_QUORUM_CONN_DIV;
 		const int quorum_shade = (live + BM_QUORUM_SHADE_DIV - 1) / BM_QUORUM_SHADE_DIV;
 		int phase; // 0 = A (DDA moves), 1 = B (candidates), 2 = C (shade / generate), 3 = D (connect)
+#if BM_POLICY == 1
+		// greedy: run the phase that serves the most lanes per instruction it costs (costs = wave-level VALU instructions of
+		// one pass, rounded); lanes waiting for an expensive phase pile up until that phase is the best deal
+		{
+			const int eA = nA * (BM_COST_B * BM_COST_C / 64), eB = nB * (BM_COST_A * BM_COST_C / 64), eC = nC * (BM_COST_A * BM_COST_B / 64);
+			const int eD = nD * (BM_COST_A * BM_COST_B / 64) * BM_COST_C / BM_COST_D;
+			phase = 0;
+			int best = eA;
+			if (eB > best) { best = eB; phase = 1; }
+			if (eC > best) { best = eC; phase = 2; }
+			if (eD > best) { best = eD; phase = 3; }
+		}
+#else
 		if (nC >= quorum_shade) phase = 2;
 		else if (nB >= quorum) phase = 1;
 		else if (nD >= quorum_conn) phase = 3;
 		else if (nA > 0) phase = 0;
 		else phase = (nC >= nB && nC >= nD) ? 2 : (nB >= nD ? 1 : 3);
+#endif
 
 		const unsigned long long t_phase = BM_TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
 		if (phase == 2) {
@@ -225,7 +271,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						cast = sunLight > 0.f;
 						terminated = !(bounces < fc.max_bounces);
 						if (terminated) {
-							accum[local_pixel].w += 1.f; // kernel.cu:301
+							acc.w += 1.f; // kernel.cu:301
 						} else {
 							// kernel.cu:281-299: cosine-weighted bounce, drawn right after the cone sample as in shade();
 							// the direction is kept in `bdir` until the shadow ray (if any) has been traced.
@@ -251,18 +297,17 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 							miss_color = c;
 						}
 					}
-					if (!is_hit || primary_only) { // the path ends here: one read-modify-write of the pixel's accumulator
-						float4 a = accum[local_pixel];
-						a.x += miss_color.x; a.y += miss_color.y; a.z += miss_color.z; // (0,0,0) for a primary-only hit
-						a.w += 1.f;
-						accum[local_pixel] = a;
+					if (!is_hit || primary_only) { // the path ends here
+						acc.x += miss_color.x; acc.y += miss_color.y; acc.z += miss_color.z; // (0,0,0) for a primary-only hit
+						acc.w += 1.f;
 						s++;
 						pstate = P_GEN;
 					}
 				}
 				if (pstate == P_GEN) {
 					if (s >= fc.spp) {
-						// pixel finished (its accumulator lives in memory and is already up to date): wait for the next one
+						// pixel finished: write its accumulator back and wait for the next one
+						accum[local_pixel] = acc;
 						if (DBG && dbg) {
 							uint32_t* d = dbg + static_cast<size_t>(local_pixel) * 8;
 							d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = hseg; d[5] = hsh; d[6] = next | (nsh << 16);
@@ -287,7 +332,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				if (need_setup) {
 					if (shadow) r.n = mk(0.f, 0.f, 0.f); // connect passes a zeroed normal (kernel.cu:338)
 					pstate = shadow ? P_SHD_DONE : P_EXT_DONE;
-					const int st = ray_setup<DBG>(sc, ro, rd, r, tally);
+					const int st = ray_setup<DBG, 1>(sc, ro, rd, r, tally);
 					state = (st == ST_NEED && shadow) ? ST_CONN : st;
 				}
 			}
@@ -307,9 +352,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					}
 				}
 				if (!occluded) {
-					float4 a = accum[local_pixel];
-					a.x += scolor.x; a.y += scolor.y; a.z += scolor.z;
-					accum[local_pixel] = a;
+					acc.x += scolor.x; acc.y += scolor.y; acc.z += scolor.z;
 				}
 				if (terminated) {
 					s++;
@@ -320,30 +363,54 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					r.n = pn;
 					shadow = false;
 					pstate = P_EXT_DONE;
-					state = ray_setup<DBG>(sc, hitp, bdir, r, tally);
+					state = ray_setup<DBG, 1>(sc, hitp, bdir, r, tally);
 				}
 			}
 		} else if (phase == 1) {
 			if (BM_TIMED) { runsB++; lanesB += nB; }
 			// ================= phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask DDA, streaming request)
 			if (state == ST_CAND) {
-				const int st = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick);
+				const int st = process_candidate<DBG, 1>(sc, fc.campos, r, info, tally, lds_brick);
 				state = (st == ST_NEED && shadow) ? ST_CONN : st;
 			}
 		} else {
-			// ================= phase A: brick-grid DDA moves; lanes that reach a non-empty cell or leave the grid wait
-#pragma unroll 1
-			for (int k = 0; k < BM_STEPS_PER_ROUND; ++k) {
-				if (BM_TIMED) { runsA++; lanesA += __popcll(__ballot(state == ST_OUTER)); }
-				if (state == ST_OUTER) {
-					const int st = outer_step<DBG>(sc, r, tally);
+			// ================= phase A: brick-grid walk; lanes that reach a non-empty cell or leave the grid wait.
+			// Walking lanes are of two kinds: ST_JUMP lanes have an empty cube of BM_JUMP_MIN cells or more ahead and cross
+			// it with one exact jump (jump.h; about four single moves' worth of instructions, ~1.5 cube edges of progress),
+			// ST_OUTER lanes are close to the surface.  With enough jumpers in the wave every walking lane takes the jump
+			// pass (a cube of edge 1-3 is crossed just the same, and a jump with n = 1 is exactly one move, valid in any
+			// cell); otherwise the lanes near the surface make a few single moves and the jumpers wait for company.
+			const int nO = nA - nJ;
+			if (nJ * BM_JUMP_RATIO >= nO) {
+				if (BM_TIMED) { runsJ++; lanesJ += nA; }
+				if (state == ST_JUMP || state == ST_OUTER) {
+					int st;
+					if (jump_possible(r.tx, r.ty, r.tz)) {
+						r.cube = r.cube ? r.cube : 1u; // a cell whose brick the ray just passed through: one plain move
+						st = field_jump<DBG>(sc, r, tally);
+					} else {
+						st = field_step<DBG>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
+					}
 					state = (st == ST_NEED && shadow) ? ST_CONN : st;
+				}
+			} else {
+#pragma unroll 1
+				for (int k = 0; k < BM_STEPS_PER_ROUND; ++k) {
+					if (BM_TIMED) { runsA++; lanesA += __popcll(__ballot(state == ST_OUTER)); }
+					if (state == ST_OUTER) {
+						const int st = field_step<DBG>(sc, r, tally);
+						state = (st == ST_NEED && shadow) ? ST_CONN : st;
+					}
 				}
 			}
 		}
 		if (BM_TIMED) {
 			const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_phase;
+#ifdef BM_TIME_REFILL
+			if (phase == 0) cycA += dt; else if (phase == 1) cycB += dt; else if (phase == 2) cycC += dt;
+#else
 			if (phase == 0) cycA += dt; else if (phase == 1) cycB += dt; else if (phase == 2) cycC += dt; else cycD += dt;
+#endif
 		}
 	}
 
@@ -359,7 +426,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	if (BM_TIMED && counters && lane == 0) {
 		const unsigned long long st[8] = {runsA, lanesA, runsB, lanesB, runsC, lanesC, runsD, lanesD};
 		for (int k = 0; k < 8; ++k) atomicAdd(&counters->sched[k], st[k]);
-		const unsigned long long cy[8] = {cycA, cycB, cycC, cycD, __builtin_amdgcn_s_memtime() - t_begin, 0ull, 0ull, 1ull};
+		const unsigned long long cy[8] = {cycA, cycB, cycC, cycD, __builtin_amdgcn_s_memtime() - t_begin, runsJ, lanesJ, 1ull};
 		for (int k = 0; k < 8; ++k) atomicAdd(&counters->cycles[k], cy[k]);
 	}
 }

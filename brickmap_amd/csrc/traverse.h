@@ -8,6 +8,7 @@
 
 #include "detmath.h"
 #include "device_types.h"
+#include "jump.h"
 
 namespace bm {
 
@@ -162,13 +163,15 @@ struct RayState {
 	float tminn;
 	f3 n;               // normal carried in/out of the traversal (voxel.cuh:135 `normal`)
 	int last_step;      // packed-cell increment of the last move (0 before the first): which axis it was, see move_axis
-	unsigned long long fine; // occupancy mask of the current 4x4x4-brick block
-	uint32_t block_base;     // arena slot of the current block's first brick
+	unsigned long long fine; // occupancy mask of the current 4x4x4-brick block   } block-mask walk only (load_block / outer_step,
+	uint32_t block_base;     // arena slot of the current block's first brick     } still used by wavefront.hip)
+	uint32_t field_off;      // cube-field walk: byte offset of the ray's octant plane in DeviceScene::cube_field
+	uint32_t cube;           // cube-field walk: edge of the empty cube ahead of the current cell (its cube_field byte)
 	float distance;     // result
 	bool hit;
 };
 
-enum : int { ST_NEED = 0, ST_OUTER = 1, ST_CAND = 2 };
+enum : int { ST_NEED = 0, ST_OUTER = 1, ST_CAND = 2, ST_JUMP = 3 };
 
 // Packed brick cell.  The three coordinates share one register, biased by one supercell (16) so that the cell just
 // outside the grid on the negative side is representable (15) and a move never borrows across fields: a move is ONE
@@ -206,9 +209,72 @@ __device__ __forceinline__ int move_axis(int last_step) {
 	return a == 0u ? -1 : (a == 1u ? 0 : (a == (1u << 11) ? 1 : 2));
 }
 
+// ---- cube-field walk.  DeviceScene::cube_field holds, per direction octant and brick cell, the edge n of the largest
+// cube of EMPTY cells that has the cell as its near corner and extends along the octant's direction (0 = the cell itself
+// holds a brick, 255 = border cell outside the grid).  A ray in that cell cannot meet a brick before one of its axes has
+// moved n cells, so the walk may take up to that many steps without looking at the grid: field_jump does it in one go,
+// landing on the bit-exact tmax values of the reference's cell-by-cell walk (jump.h); cubes too small to pay for a jump
+// are crossed by single steps.  One byte per visited cell replaces the 16-byte block record + bit test of the mask walk.
+#ifndef BM_JUMP_MIN
+#define BM_JUMP_MIN 4 // smallest cube edge worth a jump (a jump costs about four single steps)
+#endif
+__device__ __forceinline__ int field_lookup(const DeviceScene& sc, RayState& r) {
+	const uint32_t fx = r.p & 0x7FFu, fy = (r.p >> 11) & 0x7FFu, fz = r.p >> 22;
+	// bordered cell coordinate = field - 15 (16-cell bias, one border cell): the three "- 15" are folded into sc.cube_field
+	const uint32_t idx = __umul24(fz, static_cast<uint32_t>(sc.cf_xy)) + (__umul24(fy, static_cast<uint32_t>(sc.cf_x)) + fx) + r.field_off;
+	const uint32_t v = sc.cube_field[idx];
+	r.cube = v;
+	const float m = fminf(fminf(r.tx, r.ty), r.tz);
+	// select-style, no short-circuit: a branchy version costs its full instruction count in a divergent wave anyway
+	const int jump = static_cast<int>(v >= static_cast<uint32_t>(BM_JUMP_MIN)) & static_cast<int>(__float_as_uint(m) - kJumpMinBits < kJumpMaxBits - kJumpMinBits);
+	int st = jump ? ST_JUMP : ST_OUTER;
+	st = v == 0u ? ST_CAND : st;
+	st = v == 255u ? ST_NEED : st; // left the grid (voxel.cuh:256): a miss
+	return st;
+}
+
+// voxel.cuh:249-258: one Amanatides-Woo move to the next cell (select-style, see outer_step), then the new cell's byte.
+template <bool DBG>
+__device__ __forceinline__ int field_step(const DeviceScene& sc, RayState& r, Tally& tally) {
+	const float tx = r.tx, ty = r.ty, tz = r.tz;
+	const bool mx = tx < ty && tx < tz;
+	const bool my = ty <= tx && ty < tz; // mx implies !my
+	const bool mz = !(mx || my);
+	const int step_x = r.sx, step_y = r.stepy, step_z = r.stepz; // scalar copies: selects between struct members pin the struct in scratch
+	const int step = mx ? step_x : (my ? step_y : step_z);
+	r.p += static_cast<uint32_t>(step);
+	r.last_step = step;
+	r.tx = tx + (mx ? r.dx : 0.f);
+	r.ty = ty + (my ? r.dy : 0.f);
+	r.tz = tz + (mz ? r.dz : 0.f);
+	const int st = field_lookup(sc, r);
+	if (DBG && st != ST_NEED) tally.index_loads++;
+	return st;
+}
+
+// Cross the empty cube ahead of the current cell (or as much of it as the current binade of tmax allows) in one go.
+template <bool DBG>
+__device__ __forceinline__ int field_jump(const DeviceScene& sc, RayState& r, Tally& tally) {
+	uint32_t cx, cy, cz;
+	int axis;
+	float tx = r.tx, ty = r.ty, tz = r.tz;
+	const float dx = r.dx, dy = r.dy, dz = r.dz;
+	const int step_x = r.sx, step_y = r.stepy, step_z = r.stepz; // scalar copies, see field_step
+	dda_jump(tx, ty, tz, dx, dy, dz, r.cube, cx, cy, cz, axis);
+	r.tx = tx; r.ty = ty; r.tz = tz;
+	// all three products fit 24-bit signed multiplies: counts <= 255, increments +-1 / +-2^11 / +-2^22
+	r.p += static_cast<uint32_t>(__mul24(static_cast<int>(cx), step_x) + __mul24(static_cast<int>(cy), step_y) + __mul24(static_cast<int>(cz), step_z));
+	r.last_step = axis == 0 ? step_x : (axis == 1 ? step_y : step_z); // (only read after a cube exit, where it is the exit axis)
+	const int st = field_lookup(sc, r);
+	if (DBG) tally.index_loads += cx + cy + cz - (st == ST_NEED ? 1u : 0u); // the cells the reference would have loaded: all but a final one outside the grid
+	return st;
+}
+
 // voxel.cuh:136-189: clip against the world box, move onto it, set up the Amanatides-Woo state.
 // Returns the lane's next state: ST_OUTER / ST_CAND, or ST_NEED with r.hit = false when the ray misses the box.
-template <bool DBG>
+// WALK selects the empty-space structure the brick-grid walk uses: 0 = per-block occupancy masks (load_block /
+// outer_step), 1 = the octant cube field (field_lookup / field_step / field_jump below).
+template <bool DBG, int WALK = 0>
 __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const f3 dir, RayState& r, Tally& tally) {
 	r.hit = false;
 	r.d = dir;
@@ -260,8 +326,14 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 	r.tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
 	r.dx = static_cast<float>(sx) * rx; r.dy = static_cast<float>(sy) * ry; r.dz = static_cast<float>(sz) * rz;
 	r.last_step = 0;
-	load_block(sc, r); // inside the grid: never a border block
 	if (DBG) tally.index_loads++; // one per visited cell = the reference's index loads (algorithmic count)
+	if (WALK == 1) {
+		// octant of the direction: a zero component never moves, either plane is valid for it
+		const uint32_t oct = (dir.x < 0.f ? 1u : 0u) | (dir.y < 0.f ? 2u : 0u) | (dir.z < 0.f ? 4u : 0u);
+		r.field_off = oct * sc.cf_plane;
+		return field_lookup(sc, r); // inside the grid: never a border cell
+	}
+	load_block(sc, r); // inside the grid: never a border block
 	return cell_occupied(r) ? ST_CAND : ST_OUTER;
 }
 
@@ -293,7 +365,7 @@ __device__ __forceinline__ int outer_step(const DeviceScene& sc, RayState& r, Ta
 }
 
 // voxel.cuh:200-247: the current cell holds a non-empty brick -- read its index word and resolve it.
-template <bool DBG>
+template <bool DBG, int WALK = 0>
 __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const int* campos, RayState& r, HitInfo& info, Tally& tally,
 													 unsigned long long* lds_brick) {
 	const int px = cell_x(r.p), py = cell_y(r.p), pz = cell_z(r.p);
@@ -304,12 +376,22 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	// Home slot of this brick: block base + rank of its bit in the block mask.  It does not depend on the index
 	// word, so the 64-byte brick read is issued together with the index-word read instead of behind it (every
 	// non-empty cell owns its slot whether or not the brick is resident, so the read is always in bounds).
-	const int ci = cell_in_block(r.p);
-	const uint32_t slot = r.block_base + static_cast<uint32_t>(__popcll(r.fine & ((1ull << ci) - 1ull)));
-	const uint4* bq = reinterpret_cast<const uint4*>(sc.brick_arena + (static_cast<size_t>(slot) << 4));
-	const uint32_t index = sc.index_grid[flat];
+	uint32_t index, pool = 0u;
 	BrickRegs brick;
-	brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
+	if (WALK == 1) {
+		// the reference's addressing (voxel.cuh:222): pool of the supercell + the 12-bit slot carried by the index word.
+		// The pool base is read together with the index word; the brick is fetched once the word says it is resident
+		// and close enough to be walked at voxel level.
+		pool = sc.super_info[sci].brick_base;
+		index = sc.index_grid[flat];
+		brick.q0 = brick.q1 = brick.q2 = brick.q3 = make_uint4(0u, 0u, 0u, 0u);
+	} else {
+		const int ci = cell_in_block(r.p);
+		const uint32_t slot = r.block_base + static_cast<uint32_t>(__popcll(r.fine & ((1ull << ci) - 1ull)));
+		const uint4* bq = reinterpret_cast<const uint4*>(sc.brick_arena + (static_cast<size_t>(slot) << 4));
+		index = sc.index_grid[flat];
+		brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
+	}
 	// voxel.cuh:202-206, by select: entry normal and entry distance from the axis of the last move; a ray that starts
 	// inside this cell (no move yet) keeps its normal and enters at distance 0
 	const int axis = move_axis(r.last_step);
@@ -338,6 +420,10 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	} else if (index & kLoadedBit) {
 		if (DBG) tally.brick_tests++;
 		int sub = 0;
+		if (WALK == 1) {
+			const uint4* bq = reinterpret_cast<const uint4*>(sc.brick_arena + (static_cast<size_t>(pool + (index & kIndexBits)) << 4));
+			brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
+		}
 		const f3 o8 = (r.o + r.d * new_distance) * 8.f - r.n * kEpsilon;
 		if (intersect_grid<8, DBG>(o8, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick)) {
 			r.distance = new_distance * 8.f + sub_distance + r.tminn;

@@ -222,4 +222,61 @@ uint64_t World::total_bricks() const {
 	return n;
 }
 
+// Largest empty cube per cell and octant: the classic "maximal square" recurrence in 3-D.  A cube of edge n anchored at
+// c exists iff c is empty and cubes of edge n - 1 are anchored at the 7 neighbours c + {0,1}^3 * dir, so
+// E(c) = 1 + min over those neighbours, swept from the far end of the octant's direction.  The border reads as 0
+// during the sweep (a cube never leaves the grid) and is stamped 255 afterwards.
+void World::build_cube_field(std::vector<uint8_t>& field, int threads) const {
+	const int X = dims.cells + 2, Z = dims.cells_height + 2;
+	const size_t plane = static_cast<size_t>(X) * X * Z;
+	field.assign(plane * 8, 0);
+	std::vector<uint8_t> occupied(plane, 1); // border counts as occupied
+	for (int sc = 0; sc < dims.supercells; ++sc) {
+		const HostSupercell& c = supercells[sc];
+		const int sx = sc % dims.supergrid_xy, sy = (sc / dims.supergrid_xy) % dims.supergrid_xy, sz = sc / (dims.supergrid_xy * dims.supergrid_xy);
+		for (int lz = 0; lz < kSupercell; ++lz)
+			for (int ly = 0; ly < kSupercell; ++ly) {
+				uint8_t* row = &occupied[(static_cast<size_t>(sz * kSupercell + lz + 1) * X + (sy * kSupercell + ly + 1)) * X + sx * kSupercell + 1];
+				const uint32_t* words = c.indices.empty() ? nullptr : &c.indices[ly * kSupercell + lz * kSupercell * kSupercell];
+				for (int lx = 0; lx < kSupercell; ++lx) row[lx] = words && words[lx] ? 1 : 0;
+			}
+	}
+	auto sweep = [&](int oct) {
+		uint8_t* f = field.data() + plane * oct;
+		const int dx = (oct & 1) ? -1 : 1, dy = (oct & 2) ? -1 : 1, dz = (oct & 4) ? -1 : 1;
+		const ptrdiff_t ox = dx, oy = static_cast<ptrdiff_t>(dy) * X, oz = static_cast<ptrdiff_t>(dz) * X * X;
+		for (int iz = 0; iz < dims.cells_height; ++iz) {
+			const int z = dz > 0 ? dims.cells_height - iz : iz + 1; // bordered coordinate, far end first
+			for (int iy = 0; iy < dims.cells; ++iy) {
+				const int y = dy > 0 ? dims.cells - iy : iy + 1;
+				const size_t row = (static_cast<size_t>(z) * X + y) * X;
+				for (int ix = 0; ix < dims.cells; ++ix) {
+					const int x = dx > 0 ? dims.cells - ix : ix + 1;
+					const size_t i = row + x;
+					if (occupied[i]) continue; // stays 0
+					const uint8_t* n = f + i;
+					uint8_t m = n[ox];
+					m = std::min(m, n[oy]); m = std::min(m, n[ox + oy]);
+					m = std::min(m, n[oz]); m = std::min(m, n[oz + ox]); m = std::min(m, n[oz + oy]); m = std::min(m, n[oz + oy + ox]);
+					f[i] = static_cast<uint8_t>(std::min<int>(m, 253) + 1);
+				}
+			}
+		}
+		for (int z = 0; z < Z; ++z) // stamp the border
+			for (int y = 0; y < X; ++y) {
+				uint8_t* row = f + (static_cast<size_t>(z) * X + y) * X;
+				if (z == 0 || z == Z - 1 || y == 0 || y == X - 1) std::memset(row, 255, X);
+				else row[0] = row[X - 1] = 255;
+			}
+	};
+	const int n_threads = std::max(1, std::min(threads, 8));
+	std::vector<std::thread> pool;
+	std::atomic<int> next{0};
+	for (int t = 0; t < n_threads; ++t)
+		pool.emplace_back([&] {
+			for (int oct = next.fetch_add(1); oct < 8; oct = next.fetch_add(1)) sweep(oct);
+		});
+	for (auto& th : pool) th.join();
+}
+
 } // namespace bm

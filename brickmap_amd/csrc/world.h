@@ -59,6 +59,11 @@ public:
 	// CPU half of Scene::generate (Scene.cpp:118-147)
 	void generate(int threads);
 	uint64_t total_bricks() const;
+	// Octant cube field for the GPU walk (device_types.h DeviceScene::cube_field): 8 planes of
+	// (cells + 2)^2 * (cells_height + 2) bytes.  Plane o, cell c: edge (capped at 254) of the largest cube of empty
+	// cells inside the grid that has c as its near corner and extends towards -x / -y / -z where bit 0 / 1 / 2 of o is
+	// set, +x / +y / +z otherwise; 0 for a cell whose index word is non-zero, 255 for the border cells.
+	void build_cube_field(std::vector<uint8_t>& field, int threads) const;
 
 private:
 	void build_supercell(int sx, int sy, int sz, const float* heights);

@@ -94,7 +94,9 @@ typedef struct bm_sched_stats {
 	uint64_t shade_runs, shade_lanes;         /* phase C: shade / next primary ray   */
 	uint64_t connect_runs, connect_lanes;     /* phase D: connect + bounce ray setup */
 	/* shader-clock ticks spent in each phase and in the whole scheduler loop, summed over waves */
-	uint64_t step_cycles, candidate_cycles, shade_cycles, connect_cycles, total_cycles, reserved0, reserved1, waves;
+	uint64_t step_cycles, candidate_cycles, shade_cycles, connect_cycles, total_cycles;
+	uint64_t jump_runs, jump_lanes;           /* phase A, cube jumps (step_* count the single moves) */
+	uint64_t waves;
 } bm_sched_stats;
 
 /* ---- errors (replaces assert_cuda.h:5 / assert_cuda.cpp:3-13) */

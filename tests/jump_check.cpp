@@ -1,0 +1,110 @@
+// jump_check.cpp -- CPU replay test of brickmap_amd/csrc/jump.h (compiled and run by tests/test_jump.py).
+// For random rays and random points along their walk, dda_jump() must land on exactly the state that the reference's
+// one-cell-at-a-time stepping (src/voxel.cuh:249-258) reaches after the same number of steps: identical tmax bit
+// patterns, identical per-axis step counts, identical final axis.
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../brickmap_amd/csrc/jump.h"
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint32_t rnd() {
+	rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17;
+	return static_cast<uint32_t>(rng_state >> 32);
+}
+static float rndf() { return (rnd() >> 8) * (1.0f / 16777216.0f); }
+
+struct Dda {
+	float t[3], d[3];
+	// one reference step (voxel.cuh:249-258); returns the axis
+	int step() {
+		const bool mx = t[0] < t[1] && t[0] < t[2];
+		const bool my = t[1] <= t[0] && t[1] < t[2];
+		const int a = mx ? 0 : (my ? 1 : 2);
+		t[a] = t[a] + d[a];
+		return a;
+	}
+};
+
+static uint32_t bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+int main(int argc, char** argv) {
+	const long rays = argc > 1 ? std::atol(argv[1]) : 200000;
+	long jumps = 0, exits = 0, steps_total = 0, skipped_pre = 0, failures = 0;
+	long len_hist[10] = {0};
+	for (long ray = 0; ray < rays; ++ray) {
+		// direction: mostly random unit vectors, some near-axis / near-diagonal / power-of-two-slope ones (ties)
+		float dir[3];
+		const uint32_t kind = rnd() % 8;
+		for (int i = 0; i < 3; ++i) dir[i] = rndf() * 2.f - 1.f;
+		if (kind == 0) dir[rnd() % 3] *= 1e-3f;
+		if (kind == 1) { dir[0] = 1.f; dir[1] = 0.5f; dir[2] = 0.25f; }          // exact binary slopes: tdelta ties
+		if (kind == 2) { dir[0] = dir[1]; }                                       // equal components: tmax ties
+		if (kind == 3) { dir[rnd() % 3] = 0.f; }                                  // zero component: the 1e6 sentinel
+		if (kind == 4) { dir[0] = std::ldexp(1.f, -static_cast<int>(rnd() % 12)); dir[1] = std::ldexp(3.f, -static_cast<int>(rnd() % 12)); }
+		float len = std::sqrt((dir[0] * dir[0] + dir[1] * dir[1]) + dir[2] * dir[2]);
+		if (len == 0.f) continue;
+		if (kind != 1 && kind != 4) for (int i = 0; i < 3; ++i) dir[i] *= 1.0f / len;
+		float o[3];
+		for (int i = 0; i < 3; ++i) o[i] = (kind == 5 ? static_cast<float>(rnd() % 100) : rndf() * 100.f) + (kind == 6 ? 0.5f : 0.f);
+		Dda s;
+		for (int i = 0; i < 3; ++i) { // voxel.cuh:166-187
+			const int p = static_cast<int>(o[i]);
+			const float cb = dir[i] > 0.f ? static_cast<float>(p + 1) : static_cast<float>(p);
+			const float rdinv = dir[i] == 0.f ? 0.f : 1.f / dir[i];
+			const float sgn = static_cast<float>((0.f < dir[i]) - (dir[i] < 0.f));
+			s.t[i] = dir[i] != 0.f ? (cb - o[i]) * rdinv : 1000000.f;
+			s.d[i] = sgn * rdinv;
+		}
+		// walk; at random points try a jump with a random cube edge
+		const int walk = 1 + static_cast<int>(rnd() % 600);
+		for (int k = 0; k < walk; ++k) {
+			if (rnd() % 4 == 0) {
+				if (!bm::jump_possible(s.t[0], s.t[1], s.t[2])) { skipped_pre++; }
+				else {
+					const uint32_t nsel = rnd() % 4;
+					const uint32_t n = nsel == 0 ? 1 + rnd() % 4 : (nsel == 1 ? 1 + rnd() % 32 : 1 + rnd() % 254);
+					float jt[3] = {s.t[0], s.t[1], s.t[2]};
+					uint32_t c[3];
+					int last = -1;
+					const bool exited = bm::dda_jump(jt[0], jt[1], jt[2], s.d[0], s.d[1], s.d[2], n, c[0], c[1], c[2], last);
+					Dda r = s;
+					uint32_t rc[3] = {0, 0, 0};
+					int rlast = -1;
+					const uint32_t total = c[0] + c[1] + c[2];
+					bool ok = total >= 1 && total < 100000;
+					for (uint32_t q = 0; ok && q < total; ++q) { rlast = r.step(); rc[rlast]++; }
+					for (int i = 0; i < 3; ++i) ok = ok && rc[i] == c[i] && bits(r.t[i]) == bits(jt[i]) && c[i] <= n;
+					if (exited) ok = ok && rlast == last && (c[last] == n || true);
+					// a jump must not step past the cube: at most one axis reaches n, and only as the final step
+					int at_n = 0;
+					for (int i = 0; i < 3; ++i) at_n += c[i] == n;
+					ok = ok && (at_n == 0 || (exited && at_n == 1 && c[last] == n));
+					if (!ok) {
+						if (failures < 10)
+							std::fprintf(stderr, "MISMATCH ray %ld n %u t=(%a %a %a) d=(%a %a %a) jump c=(%u %u %u) last %d exited %d -> t=(%a %a %a); replay c=(%u %u %u) last %d t=(%a %a %a)\n",
+										 ray, n, s.t[0], s.t[1], s.t[2], s.d[0], s.d[1], s.d[2], c[0], c[1], c[2], last, exited, jt[0], jt[1], jt[2], rc[0], rc[1], rc[2], rlast,
+										 r.t[0], r.t[1], r.t[2]);
+						failures++;
+					}
+					jumps++;
+					exits += exited;
+					steps_total += total;
+					int l = 0;
+					while ((1u << l) < total && l < 9) l++;
+					len_hist[l]++;
+				}
+			}
+			s.step();
+		}
+	}
+	std::printf("jumps %ld exits %ld steps %ld (%.1f per jump) precondition-skips %ld failures %ld\n", jumps, exits, steps_total, jumps ? double(steps_total) / jumps : 0.0,
+				skipped_pre, failures);
+	std::printf("jump length histogram (<=1,2,4,...):");
+	for (int i = 0; i < 10; ++i) std::printf(" %ld", len_hist[i]);
+	std::printf("\n");
+	return failures ? 1 : 0;
+}

@@ -447,9 +447,11 @@ def test_scheduler_statistics(bm, orc, torch_cuda, scene256):
     scene256.counters_reset()
     gpu_render(bm, torch_cuda, scene256, cam, bm.FrameParams(128, 96, spp=2, max_bounces=3, flags=bm.BM_FLAG_COUNTERS), want_dbg=False)
     c, s = scene256.counters(), scene256.sched_stats()
-    assert s["step_lanes"] + c["extend_rays"] + c["shadow_rays"] >= c["index_loads"]  # every visited cell is a move or a ray start
+    # a visited cell is a ray start, a single move, or one of the (at most 3 * 254) cells crossed by a jump
+    assert s["step_lanes"] + 762 * s["jump_lanes"] + c["extend_rays"] + c["shadow_rays"] >= c["index_loads"]
+    assert s["step_lanes"] + s["jump_lanes"] + c["extend_rays"] + c["shadow_rays"] < c["index_loads"]  # jumps do skip cells
     assert s["candidate_lanes"] >= c["brick_tests"] and s["shade_lanes"] >= c["extend_rays"] and s["connect_lanes"] == c["shadow_rays"]
-    assert 0 < s["step_lanes"] <= 64 * s["step_runs"] and s["waves"] > 0
+    assert 0 <= s["step_lanes"] <= 64 * s["step_runs"] and 0 < s["jump_lanes"] <= 64 * s["jump_runs"] and s["waves"] > 0
 
 
 def test_randomised_views_match_oracle(bm, orc, torch_cuda, scene256, world256):

@@ -20,4 +20,5 @@ for k in ("step", "candidate", "shade", "connect"):
     r, l = s[k+"_runs"], s[k+"_lanes"]
     cy = s[k+"_cycles"]
     print("%-10s runs %10d  avg active lanes %5.1f   cycles/run %8.1f   share of wave time %5.1f%%" % (k, r, l/max(r,1), cy/max(r,1), 100.0*cy/s["total_cycles"]))
+print("jump       runs %10d  avg active lanes %5.1f" % (s["jump_runs"], s["jump_lanes"]/max(s["jump_runs"],1)))
 print("waves", s["waves"], "avg wave cycles", s["total_cycles"]/s["waves"])
