@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbrickmap_hip.so")
 
 BM_FLAG_PRIMARY_ONLY = 1
+BM_FLAG_SAMPLE_ITEMS = 4
 BM_FLAG_COUNTERS = 2
 BRICK_INDEX_BITS = 0x00000FFF
 BRICK_LOD_BITS = 0x000FF000
@@ -88,6 +89,7 @@ SIGNATURES = {
     "bm_scene_column_heights": (_i, [_vp, _i, _i, _vp]),
     "bm_host_column_heights": (_i, [_i, _i, _i, _i, _vp]),
     "bm_host_generate_supercell": (_i, [_i, _i, _i, _i, _i, _vp, _u32p, _vp, C.c_uint32]),
+    "bm_host_cube_field": (_i, [_i, _i, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "bm_buffer_alloc": (_i, [_i, C.c_size_t, C.POINTER(_vp)]),
     "bm_buffer_free": (_i, [_i, _vp]),
     "bm_buffer_zero": (_i, [_i, _vp, C.c_size_t, _vp]),

@@ -1,5 +1,6 @@
 // capi.cpp -- extern "C" surface of libbrickmap_hip.so (declared in include/brickmap.h).
 #include <cstring>
+#include <vector>
 #include <new>
 
 #include "kernels.h"
@@ -126,6 +127,20 @@ int bm_host_generate_supercell(int grid_size, int grid_height, int sx, int sy, i
 		const size_t n = c.bricks.size() < brick_capacity ? c.bricks.size() : brick_capacity;
 		std::memcpy(bricks, c.bricks.data(), n * sizeof(bm::Brick));
 	}
+	return 0;
+}
+
+int bm_host_cube_field(int grid_size, int grid_height, uint8_t* field, size_t capacity, size_t* bytes) {
+	bm::World w;
+	if (!w.dims.set(grid_size, grid_height)) { set_error("bad world dimensions"); return BM_EINVAL; }
+	const size_t need = 8ull * (w.dims.cells + 2) * (w.dims.cells + 2) * (w.dims.cells_height + 2);
+	if (bytes) *bytes = need;
+	if (!field) return 0;
+	if (capacity < need) { set_error("cube field buffer too small"); return BM_EINVAL; }
+	w.generate(8);
+	std::vector<uint8_t> f;
+	w.build_cube_field(f, 8);
+	std::memcpy(field, f.data(), need);
 	return 0;
 }
 

@@ -51,6 +51,11 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp,
 		set_error("bad frame parameters");
 		return BM_EINVAL;
 	}
+	// the kernels pack a pixel as x | y << 16 and index the shard's packed buffers with 32-bit pixel numbers
+	if (fp->width > 65535 || fp->height > 65535 || static_cast<long long>(bm_local_rows(fp)) * fp->width >= (1ll << 32)) {
+		set_error("frame too large: width and height are limited to 65535 and a shard to 2^32 pixels");
+		return BM_EINVAL;
+	}
 	std::memset(fc, 0, sizeof *fc);
 	const V3 dir{cam->direction[0], cam->direction[1], cam->direction[2]};
 	const V3 upv{cam->up[0], cam->up[1], cam->up[2]};
@@ -412,9 +417,18 @@ int Scene::service_ring(int ring, uint32_t count) {
 	if (upload_pending_) BM_HIP(hipEventSynchronize(ev_upload_)); // the staging buffers of the previous upload are free again
 	for (uint32_t i = 0; i < count; ++i) {
 		const int px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+		// the positions come back from device memory: never index host arrays with an entry that cannot be a request
+		if (px < 0 || py < 0 || pz < 0 || px >= d.cells || py >= d.cells || pz >= d.cells_height) {
+			set_error("brick request ring holds a position outside the world");
+			return BM_ESTATE;
+		}
 		HostSupercell& c = world.supercells[d.supercell_id(px / kSupercell, py / kSupercell, pz / kSupercell)];
 		const uint32_t local = static_cast<uint32_t>((px % kSupercell) + (py % kSupercell) * kSupercell + (pz % kSupercell) * kSupercell * kSupercell);
 		const uint32_t word = c.indices[local];
+		if (!(word & BM_BRICK_LOADED_BIT) || (word & BM_BRICK_INDEX_BITS) >= c.bricks.size()) {
+			set_error("brick request ring names an empty brick");
+			return BM_ESTATE;
+		}
 		std::memcpy(h_bricks_ + static_cast<size_t>(i) * kBrickWords, c.bricks[word & BM_BRICK_INDEX_BITS].data, sizeof(Brick));
 		// the reference hands out slots in request order (gpu_index_highest++, Scene.cpp:224); here every brick has a
 		// fixed home slot in the exact-fit arena (block order), so the new index word carries that slot
@@ -447,7 +461,7 @@ int Scene::process_load_queue(uint32_t* serviced) {
 	if (!overlapped_) {
 		// ---- reference order (main.cpp:142-144): the frame that raised the requests has finished (kernel.cu:431), the host
 		// reads the ring, stages, uploads; the next frame sees the bricks
-		if (any_frame()) BM_HIP(hipStreamSynchronize(last_stream_)); // nullptr = the default stream
+		if (any_frame()) BM_HIP(hipEventSynchronize(ev_frame_done_)); // recorded behind the last frame on whatever stream it ran
 		BM_HIP(hipMemcpyAsync(h_count_[0], d_load_count_[0], sizeof(uint32_t), hipMemcpyDeviceToHost, load_stream_)); // Scene.cpp:202
 		BM_HIP(hipStreamSynchronize(load_stream_));
 		const uint32_t count = std::min<uint32_t>(static_cast<uint32_t>(queue_cap_), *h_count_[0]);                   // Scene.cpp:203
@@ -461,7 +475,6 @@ int Scene::process_load_queue(uint32_t* serviced) {
 	// ---- overlapped mode: never wait for the GPU.  (1) service the ring that was copied out by the previous call,
 	// (2) start copying out the ring the last frame wrote, behind that frame, on the load stream, (3) hand the other
 	// ring to the next frame.  Request -> resident takes two frames, as in the reference.
-	if (any_frame()) BM_HIP(hipEventRecord(ev_frame_done_, last_stream_)); // "the last frame has finished", for the load stream
 	if (snapshot_pending_) {
 		BM_HIP(hipEventSynchronize(ev_snapshot_));
 		snapshot_pending_ = false;
@@ -542,10 +555,15 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 		BM_HIP(hipStreamWaitEvent(stream, ev_upload_, 0));
 		upload_pending_ = false;
 	}
+	if (dbg && (fp->flags & BM_FLAG_SAMPLE_ITEMS)) { set_error("hit records are per pixel: not available with BM_FLAG_SAMPLE_ITEMS"); return BM_EINVAL; }
 	const bool instrumented = dbg != nullptr || (fp->flags & BM_FLAG_COUNTERS);
 	const int slot = static_cast<int>(launches_ % kTimingRing);
 	BM_HIP(hipMemsetAsync(d_work_counter_, 0, kWorkCounterBytes, stream)); // chunk counters of the persistent kernel
-	h_frame_constants_[slot] = fc; // (a slot is reused only after kTimingRing further launches)
+	// the pinned slot (and its event pair) is reused every kTimingRing launches: make sure the launch that used it last has
+	// consumed it -- a caller that queues hundreds of frames without a sync would otherwise overwrite constants whose copy
+	// has not run yet (the event is almost always complete already, so this costs nothing)
+	if (launches_ >= kTimingRing) BM_HIP(hipEventSynchronize(ev_stop_[slot]));
+	h_frame_constants_[slot] = fc;
 	BM_HIP(hipMemcpyAsync(d_frame_constants_ + slot, h_frame_constants_ + slot, sizeof(FrameConstants), hipMemcpyHostToDevice, stream));
 	BM_HIP(hipEventRecord(ev_start_[slot], stream));
 #ifdef BM_PHASE_TIMING
@@ -557,8 +575,8 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 				 compute_units_ * blocks_per_cu_[instrumented ? 1 : 0], stream);
 	BM_HIP(hipGetLastError());
 	BM_HIP(hipEventRecord(ev_stop_[slot], stream));
+	BM_HIP(hipEventRecord(ev_frame_done_, stream)); // what process_load_queue waits for (the caller's stream may be gone by then)
 	launches_++;
-	last_stream_ = stream;
 	return 0;
 }
 
@@ -576,7 +594,7 @@ int Scene::begin_frame(hipStream_t stream, DeviceScene* view, DeviceCounters** c
 
 void Scene::end_frame(hipStream_t stream) {
 	other_frames_++;
-	last_stream_ = stream;
+	(void)hipEventRecord(ev_frame_done_, stream);
 }
 
 int Scene::resolve(const float* accum, float* out, long long n, hipStream_t stream) {
@@ -584,7 +602,6 @@ int Scene::resolve(const float* accum, float* out, long long n, hipStream_t stre
 	BM_HIP(hipSetDevice(device_));
 	launch_resolve(accum, out, n, stream);
 	BM_HIP(hipGetLastError());
-	last_stream_ = stream;
 	return 0;
 }
 

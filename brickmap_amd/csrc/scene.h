@@ -52,7 +52,7 @@ public:
 	int sched_stats_read(bm_sched_stats* out);
 
 	// Hooks for a frame issued by other code on this scene (the wavefront mode): begin_frame orders `stream` behind
-	// pending brick uploads and hands out the current device view; end_frame records the stream for process_load_queue.
+	// pending brick uploads and hands out the current device view; end_frame records the "frame done" event process_load_queue waits for.
 	int begin_frame(hipStream_t stream, DeviceScene* view, DeviceCounters** counters);
 	void end_frame(hipStream_t stream);
 	int compute_units() const { return compute_units_; }
@@ -78,7 +78,6 @@ private:
 	long long other_frames_ = 0;   // frames issued through begin_frame / end_frame
 	bool any_frame() const { return launches_ + other_frames_ > 0; }
 	bool upload_pending_ = false;
-	hipStream_t last_stream_ = nullptr;
 
 	// device memory (DeviceScene view)
 	uint32_t* d_index_grid_ = nullptr;

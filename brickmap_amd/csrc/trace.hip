@@ -42,6 +42,12 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_WORK_COUNTERS
 #define BM_WORK_COUNTERS 8
 #endif
+#ifndef BM_QUORUM_NUM
+#define BM_QUORUM_NUM 1
+#endif
+#ifndef BM_QUORUM_SHADE_NUM
+#define BM_QUORUM_SHADE_NUM 1
+#endif
 #ifndef BM_QUORUM_DIV
 #define BM_QUORUM_DIV 2
 #endif
@@ -72,9 +78,6 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_REFILL_MIN
 #define BM_REFILL_MIN 16
 #endif
-#ifndef BM_JUMP_RATIO
-#define BM_JUMP_RATIO 4 // a move round is a jump pass when (lanes with a cube ahead) * ratio >= (lanes near the surface)
-#endif
 // -DBM_PHASE_TIMING: profiling build in which the plain kernel also reports the scheduler statistics
 #ifdef BM_PHASE_TIMING
 #define BM_TIMED true
@@ -93,6 +96,13 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	const int lane = threadIdx.x & 63;
 	const uint32_t W = static_cast<uint32_t>(fc.width), H = static_cast<uint32_t>(fc.height);
 	const uint32_t total_chunks = static_cast<uint32_t>(fc.tiles_x) * static_cast<uint32_t>(fc.tiles_y) * 16u;
+	// Work items.  Default: a lane traces ALL samples of its pixel in order (fixed accumulation order per pixel, one plain
+	// write-back).  BM_FLAG_SAMPLE_ITEMS: the item is ONE sample of a 4x4 chunk -- spp times more, spp times shorter items,
+	// which keeps the persistent waves fed when a shard has few pixels and many samples (the 1/N row-band shards of a
+	// multi-GPU frame); samples of one pixel then run on different lanes and are added with float atomics like the
+	// reference does (kernel.cu:319-322,341-343), so radiance is equal up to summation order.
+	const bool sample_items = (fc.flags & 4u) != 0u; // BM_FLAG_SAMPLE_ITEMS
+	const uint32_t items_per_chunk = sample_items ? static_cast<uint32_t>(fc.spp > 0 ? fc.spp : 1) : 1u;
 
 	// per-pixel state
 	uint32_t xy = 0;          // x | y << 16
@@ -108,6 +118,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	int state = ST_IDLE;
 	int pstate = P_GEN;
 	int s = 0;               // sample being traced
+	int s_end = 0;           // first sample that is no longer this lane's
 	int bounces = 0;
 	bool shadow = false;     // kind of the ray in flight
 	bool terminated = false; // path ends after its pending shadow ray
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			const uint32_t total_groups = (total_chunks + 3u) >> 2;
 			const uint32_t my_groups = total_groups > static_cast<uint32_t>(my_counter)
 										   ? (total_groups - static_cast<uint32_t>(my_counter) + kCounters - 1u) / kCounters : 0u;
-			const uint32_t my_tickets = my_groups * 4u;
+			const uint32_t my_tickets = my_groups * 4u * items_per_chunk; // consecutive tickets = the samples of one chunk
 			const uint32_t counter_now = static_cast<uint32_t>(my_counter);
 			if (base + want >= my_tickets) { // this counter is used up: move to the next one (helping out), or finish
 				my_counter = (my_counter + 1) % static_cast<int>(kCounters);
@@ -159,9 +170,10 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			}
 			const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
 			if (state == ST_IDLE && rank < want * 16) {
-				const uint32_t ticket = base + static_cast<uint32_t>(rank >> 4);
+				const uint32_t item = base + static_cast<uint32_t>(rank >> 4);
+				const uint32_t ticket = item / items_per_chunk, item_sample = item - ticket * items_per_chunk;
 				const uint32_t chunk = ((ticket >> 2) * kCounters + counter_now) * 4u + (ticket & 3u);
-				if (ticket < my_tickets && chunk < total_chunks) {
+				if (item < my_tickets && chunk < total_chunks) {
 					const uint32_t tile = chunk >> 4, k = chunk & 15u;
 					const int tile_x = static_cast<int>(tile % static_cast<uint32_t>(fc.tiles_x));
 					const int tile_y = static_cast<int>(tile / static_cast<uint32_t>(fc.tiles_x));
@@ -173,10 +185,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						p = static_cast<uint32_t>(y) * W + static_cast<uint32_t>(x);
 						local_pixel = static_cast<uint32_t>(ly) * W + static_cast<uint32_t>(x);
 						xy = static_cast<uint32_t>(x) | (static_cast<uint32_t>(y) << 16);
-						s = 0;
+						s = sample_items ? static_cast<int>(item_sample) : 0;
+						s_end = sample_items ? s + 1 : fc.spp;
 						pstate = P_GEN;
 						state = ST_NEED;
-						acc = accum[local_pixel];
+						acc = sample_items ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[local_pixel];
 						if (DBG) {
 							d0 = 0; d1 = 0; d2 = 0xFFFFFFFFu; d3 = 0; hseg = 2166136261u; hsh = 2166136261u; next = 0; nsh = 0;
 							loads0 = tally.index_loads;
@@ -201,8 +214,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		if (--rounds_left < 0) break;
 		// Policy: an expensive phase runs once a quarter of the live lanes wait for it, the cheap connect phase
 		// once an eighth does; otherwise the DDA keeps moving.  With no lane left in the DDA the largest group runs.
-		const int quorum = (live + BM_QUORUM_DIV - 1) / BM_QUORUM_DIV, quorum_conn = (live + BM_QUORUM_CONN_DIV - 1) / BM_QUORUM_CONN_DIV;
-		const int quorum_shade = (live + BM_QUORUM_SHADE_DIV - 1) / BM_QUORUM_SHADE_DIV;
+		const int quorum = (live * BM_QUORUM_NUM + BM_QUORUM_DIV - 1) / BM_QUORUM_DIV, quorum_conn = (live + BM_QUORUM_CONN_DIV - 1) / BM_QUORUM_CONN_DIV;
+		const int quorum_shade = (live * BM_QUORUM_SHADE_NUM + BM_QUORUM_SHADE_DIV - 1) / BM_QUORUM_SHADE_DIV;
 		int phase; // 0 = A (DDA moves), 1 = B (candidates), 2 = C (shade / generate), 3 = D (connect)
 #if BM_POLICY == 1
 		// greedy: run the phase that serves the most lanes per instruction it costs (costs = wave-level VALU instructions of
@@ -305,9 +318,14 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					}
 				}
 				if (pstate == P_GEN) {
-					if (s >= fc.spp) {
-						// pixel finished: write its accumulator back and wait for the next one
-						accum[local_pixel] = acc;
+					if (s >= s_end) {
+						// item finished: write the accumulator back (or add this sample's share) and wait for the next one
+						if (sample_items) {
+							float* a = reinterpret_cast<float*>(accum + local_pixel);
+							unsafeAtomicAdd(a + 0, acc.x); unsafeAtomicAdd(a + 1, acc.y); unsafeAtomicAdd(a + 2, acc.z); unsafeAtomicAdd(a + 3, acc.w);
+						} else {
+							accum[local_pixel] = acc;
+						}
 						if (DBG && dbg) {
 							uint32_t* d = dbg + static_cast<size_t>(local_pixel) * 8;
 							d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = hseg; d[5] = hsh; d[6] = next | (nsh << 16);

@@ -270,6 +270,36 @@ __device__ __forceinline__ int field_jump(const DeviceScene& sc, RayState& r, Ta
 	return st;
 }
 
+// One round of the brick-grid walk for a wave (used by the queue kernels of wavefront.hip; trace.hip inlines the same
+// policy into its scheduler).  Walking lanes are of two kinds: ST_JUMP lanes have an empty cube of BM_JUMP_MIN cells or
+// more ahead, ST_OUTER lanes are close to the surface.  With enough jumpers every walking lane takes the jump pass (a
+// cube of edge 1-3 is crossed just the same, and a jump with n = 1 is exactly one move, valid in any cell); otherwise the
+// lanes near the surface make STEPS single moves and the jumpers wait for company.  runs / lanes: DBG statistics.
+#ifndef BM_JUMP_RATIO
+#define BM_JUMP_RATIO 4 // a move round is a jump pass when (lanes with a cube ahead) * ratio >= (lanes near the surface)
+#endif
+template <bool DBG, int STEPS>
+__device__ __forceinline__ int walk_round(const DeviceScene& sc, RayState& r, int state, int n_jump, int n_outer, Tally& tally, uint32_t& runs, uint32_t& lanes) {
+	if (n_jump * BM_JUMP_RATIO >= n_outer) {
+		if (DBG) { runs++; lanes += static_cast<uint32_t>(n_jump + n_outer); }
+		if (state == ST_JUMP || state == ST_OUTER) {
+			if (jump_possible(r.tx, r.ty, r.tz)) {
+				r.cube = r.cube ? r.cube : 1u; // a cell whose brick the ray just passed through: one plain move
+				state = field_jump<DBG>(sc, r, tally);
+			} else {
+				state = field_step<DBG>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
+			}
+		}
+	} else {
+#pragma unroll 1
+		for (int k = 0; k < STEPS; ++k) {
+			if (DBG) { runs++; lanes += static_cast<uint32_t>(__popcll(__ballot(state == ST_OUTER))); }
+			if (state == ST_OUTER) state = field_step<DBG>(sc, r, tally);
+		}
+	}
+	return state;
+}
+
 // voxel.cuh:136-189: clip against the world box, move onto it, set up the Amanatides-Woo state.
 // Returns the lane's next state: ST_OUTER / ST_CAND, or ST_NEED with r.hit = false when the ray misses the box.
 // WALK selects the empty-space structure the brick-grid walk uses: 0 = per-block occupancy masks (load_block /

@@ -15,6 +15,7 @@ Wavefront::~Wavefront() {
 	(void)hipFree(d_frame_constants_);
 	if (h_frame_constants_) (void)hipHostFree(h_frame_constants_);
 	for (auto& e : ev_) if (e) (void)hipEventDestroy(e);
+	for (auto& e : ev_slot_) if (e) (void)hipEventDestroy(e);
 }
 
 int Wavefront::init() {
@@ -35,6 +36,7 @@ int Wavefront::init() {
 	BM_HIP(hipMalloc(&d_counters_, 2 * sizeof(DeviceCounters)));
 	BM_HIP(hipMemset(d_counters_, 0, 2 * sizeof(DeviceCounters)));
 	for (auto& e : ev_) BM_HIP(hipEventCreate(&e));
+	for (auto& e : ev_slot_) BM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	for (int c = 0; c < 2; ++c)
 		for (int i = 0; i < 2; ++i) blocks_per_cu_[c][i] = std::min(wavefront_blocks_per_cu(c != 0, i != 0), kMaxBlocksPerCu);
 	if (const char* cap = std::getenv("BM_WF_BLOCKS_PER_CU")) { // experiment knob: fewer resident waves per SIMD
@@ -68,6 +70,8 @@ int Wavefront::frame(const bm_camera* cam, const bm_frame_params* fp, float* acc
 	DeviceCounters* const counters_extend = instrumented ? d_counters_ : nullptr;
 	DeviceCounters* const counters_connect = instrumented ? d_counters_ + 1 : nullptr;
 	const int slot = static_cast<int>(frame_ % kConstantsRing);
+	// the pinned slot is reused every kConstantsRing frames: wait until the copy that read it last has run (see Scene::render)
+	if (slot_used_[slot]) BM_HIP(hipEventSynchronize(ev_slot_[slot]));
 	h_frame_constants_[slot] = fc;
 	const FrameConstants* fc_dev = d_frame_constants_ + slot;
 	BM_HIP(hipMemcpyAsync(d_frame_constants_ + slot, h_frame_constants_ + slot, sizeof(FrameConstants), hipMemcpyHostToDevice, stream));
@@ -85,6 +89,8 @@ int Wavefront::frame(const bm_camera* cam, const bm_frame_params* fp, float* acc
 	BM_HIP(hipEventRecord(ev_[3], stream));
 	launch_wf_trace(true, view, fc_dev, d_state_, d_work_, d_shadow_, accum, counters_connect, queue_size_, cus * blocks_per_cu_[1][instrumented ? 1 : 0], d_cold_, stream);
 	BM_HIP(hipEventRecord(ev_[4], stream));
+	BM_HIP(hipEventRecord(ev_slot_[slot], stream)); // this frame's kernels have read the device copy of the constants
+	slot_used_[slot] = true;
 	BM_HIP(hipGetLastError());
 	timed_ = true;
 	frame_++;

@@ -40,6 +40,8 @@ private:
 	FrameConstants* d_frame_constants_ = nullptr;
 	FrameConstants* h_frame_constants_ = nullptr;
 	hipEvent_t ev_[5] = {};
+	hipEvent_t ev_slot_[kConstantsRing] = {}; // "the frame that used this constants slot has finished"
+	bool slot_used_[kConstantsRing] = {};
 	bool timed_ = false;
 	// resident workgroups per CU of the persistent kernels: the walk is instruction-bound, throughput saturates at 5 waves
 	// per SIMD (2 / 3 / 4 / 5 / 6: 1546 / 1851 / 2014 / 2072 / 2062 Mrays/s) and a 6th only lengthens the tail

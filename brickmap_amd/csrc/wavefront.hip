@@ -38,7 +38,7 @@ namespace bm {
 #define BM_WF_TRACE wf_trace
 #endif
 #ifndef BM_WF_STEPS
-#define BM_WF_STEPS 8
+#define BM_WF_STEPS 4
 #endif
 
 
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256, DBG ? 4 : 6) void wf_trace(const DeviceScene s
 		}
 		const unsigned long long need = __ballot(state == ST_NEED);
 		const int nN = __popcll(need);
-		const int nA = __popcll(__ballot(state == ST_OUTER));
+		const int nJ = __popcll(__ballot(state == ST_JUMP));
+		const int nA = __popcll(__ballot(state == ST_OUTER)) + nJ; // walking lanes: cell by cell (ST_OUTER) or cube by cube (ST_JUMP)
 		const int nB = __popcll(__ballot(state == ST_CAND));
 		const bool more = work_left || cur < end;
 		if (--rounds_left < 0) break;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256, DBG ? 4 : 6) void wf_trace(const DeviceScene s
 						r.n = mk(c.y, c.z, c.w);
 					}
 					have = true;
-					state = ray_setup<DBG>(sc, o, d, r, tally);
+					state = ray_setup<DBG, 1>(sc, o, d, r, tally);
 				}
 				cur += take;
 			}
@@ -183,14 +184,11 @@ __global__ __launch_bounds__(256, DBG ? 4 : 6) void wf_trace(const DeviceScene s
 		if (nB >= (live + BM_WF_QUORUM_DIV - 1) / BM_WF_QUORUM_DIV || nA == 0) {
 			// ---- phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask walk, streaming request)
 			if (DBG) { runsB++; lanesB += nB; }
-			if (state == ST_CAND) state = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick);
+			if (state == ST_CAND) state = process_candidate<DBG, 1>(sc, fc.campos, r, info, tally, lds_brick);
 		} else {
-			// ---- phase A: brick-grid moves
-#pragma unroll 1
-			for (int k = 0; k < BM_WF_STEPS; ++k) {
-				if (DBG) { runsA++; lanesA += __popcll(__ballot(state == ST_OUTER)); }
-				if (state == ST_OUTER) state = outer_step<DBG>(sc, r, tally);
-			}
+			// ---- phase A: brick-grid walk (trace.hip phase A): a jump pass for every walking lane when enough of them have
+			// an empty cube ahead, single moves otherwise
+			state = walk_round<DBG, BM_WF_STEPS>(sc, r, state, nJ, nA - nJ, tally, runsA, lanesA);
 		}
 	}
 
@@ -220,7 +218,7 @@ __global__ __launch_bounds__(256, DBG ? 4 : 6) void wf_trace(const DeviceScene s
 // brick units, entry distance; the direction is in the queue record) is parked in a per-slot global scratch record.
 // What a ray computes is unchanged (same device functions, same operands, results written per queue slot).
 #ifndef BM_WG_STEPS
-#define BM_WG_STEPS 10 // brick-grid moves per phase
+#define BM_WG_STEPS 4 // single brick-grid moves per phase (when the wave is not jumping)
 #endif
 #ifndef BM_WG_PERIOD
 #define BM_WG_PERIOD 4 // phases a wave runs between two redistributions (1: 1.08 ms, 2: 1.02, 3-4: 1.01, 6: 1.03 per config-2 frame)
@@ -231,7 +229,7 @@ __global__ __launch_bounds__(256, DBG ? 4 : 6) void wf_trace(const DeviceScene s
 #ifndef BM_WG_GRAB
 #define BM_WG_GRAB 256 // queue slots a workgroup reserves per ticket atomic
 #endif
-constexpr int kPoolFields = 15;
+constexpr int kPoolFields = 17;
 
 template <bool CONNECT, bool DBG>
 __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScene sc, const FrameConstants* __restrict__ fcp, WfState* __restrict__ st,
@@ -240,7 +238,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScen
 	const FrameConstants& fc = *fcp;
 	__shared__ unsigned long long lds_brick[8 * 256];
 	__shared__ uint32_t pool[kPoolFields][256];
-	__shared__ uint32_t wave_cnt[2][4]; // rays that want moves / candidate resolution, per wave
+	__shared__ uint32_t wave_cnt[3][4]; // rays that want a cube jump / single moves / candidate resolution, per wave
 	__shared__ uint32_t s_base, s_take, s_more;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t total = CONNECT ? st->shadow_ray_cnt : queue_size;
@@ -249,8 +247,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScen
 	RayState r;
 	r.hit = false;
 	r.n = mk(0.f, 0.f, 0.f);
-	r.fine = 0ull;
-	r.block_base = 0u;
+	r.field_off = 0u;
+	r.cube = 0u;
 	Tally tally;
 	HitInfo info;
 	int state = ST_NEED;
@@ -279,26 +277,32 @@ __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScen
 			}
 		}
 		// ---- stable partition of the workgroup's live rays: moving, then candidates; slot = position in that order
-		const bool isO = state == ST_OUTER, isC = state == ST_CAND;
-		const unsigned long long bO = __ballot(isO), bC = __ballot(isC);
-		if (lane == 0) { wave_cnt[0][wave] = static_cast<uint32_t>(__popcll(bO)); wave_cnt[1][wave] = static_cast<uint32_t>(__popcll(bC)); }
-		__syncthreads();
-		uint32_t nO = 0, nC = 0, preO = 0, preC = 0;
-		for (int w = 0; w < 4; ++w) {
-			const uint32_t o = wave_cnt[0][w], c = wave_cnt[1][w];
-			if (w < wave) { preO += o; preC += c; }
-			nO += o; nC += c;
+		// three classes, so that waves become homogeneous in the kind of walk as well: cube jumps, single moves, candidates
+		const bool isJ = state == ST_JUMP, isO = state == ST_OUTER, isC = state == ST_CAND;
+		const unsigned long long bJ = __ballot(isJ), bO = __ballot(isO), bC = __ballot(isC);
+		if (lane == 0) {
+			wave_cnt[0][wave] = static_cast<uint32_t>(__popcll(bJ)); wave_cnt[1][wave] = static_cast<uint32_t>(__popcll(bO));
+			wave_cnt[2][wave] = static_cast<uint32_t>(__popcll(bC));
 		}
-		const uint32_t live = nO + nC;
+		__syncthreads();
+		uint32_t nJ = 0, nO = 0, nC = 0, preJ = 0, preO = 0, preC = 0;
+		for (int w = 0; w < 4; ++w) {
+			const uint32_t j = wave_cnt[0][w], o = wave_cnt[1][w], c = wave_cnt[2][w];
+			if (w < wave) { preJ += j; preO += o; preC += c; }
+			nJ += j; nO += o; nC += c;
+		}
+		const uint32_t live = nJ + nO + nC;
 		const unsigned long long below = (1ull << lane) - 1ull;
-		if (isO || isC) {
-			const uint32_t dest = isO ? preO + static_cast<uint32_t>(__popcll(bO & below)) : nO + preC + static_cast<uint32_t>(__popcll(bC & below));
+		if (isJ || isO || isC) {
+			const uint32_t dest = isJ ? preJ + static_cast<uint32_t>(__popcll(bJ & below))
+									  : (isO ? nJ + preO + static_cast<uint32_t>(__popcll(bO & below)) : nJ + nO + preC + static_cast<uint32_t>(__popcll(bC & below)));
 			pool[0][dest] = __float_as_uint(r.tx); pool[1][dest] = __float_as_uint(r.ty); pool[2][dest] = __float_as_uint(r.tz);
 			pool[3][dest] = __float_as_uint(r.dx); pool[4][dest] = __float_as_uint(r.dy); pool[5][dest] = __float_as_uint(r.dz);
 			pool[6][dest] = r.p; pool[7][dest] = static_cast<uint32_t>(r.sx); pool[8][dest] = static_cast<uint32_t>(r.stepy);
 			pool[9][dest] = static_cast<uint32_t>(r.stepz);
 			pool[10][dest] = __float_as_uint(r.n.x); pool[11][dest] = __float_as_uint(r.n.y); pool[12][dest] = __float_as_uint(r.n.z);
 			pool[13][dest] = static_cast<uint32_t>(r.last_step); pool[14][dest] = idx;
+			pool[15][dest] = r.field_off; pool[16][dest] = r.cube;
 		}
 		if (tid == 0) { // hand out queue slots to the empty lanes (threads live .. 255) from the workgroup's private range
 			if (cur == end && more) {
@@ -323,8 +327,10 @@ __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScen
 			r.stepz = static_cast<int>(pool[9][tid]);
 			r.n = mk(__uint_as_float(pool[10][tid]), __uint_as_float(pool[11][tid]), __uint_as_float(pool[12][tid]));
 			r.last_step = static_cast<int>(pool[13][tid]); idx = pool[14][tid];
+			r.field_off = pool[15][tid];
+			r.cube = pool[16][tid];
 			r.hit = false;
-			state = static_cast<uint32_t>(tid) < nO ? ST_OUTER : ST_CAND;
+			state = static_cast<uint32_t>(tid) < nJ ? ST_JUMP : (static_cast<uint32_t>(tid) < nJ + nO ? ST_OUTER : ST_CAND);
 		} else {
 			state = ST_NEED;
 			// ---- refill: the empty lanes are the last threads of the workgroup
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScen
 					d = mk(u.w, v.x, v.y);
 					r.n = mk(w2.y, w2.z, w2.w);
 				}
-				state = ray_setup<DBG>(sc, o, d, r, tally);
+				state = ray_setup<DBG, 1>(sc, o, d, r, tally);
 				ended = state == ST_NEED; // missed the world box
 				if (!ended) cold[idx] = make_float4(r.o.x, r.o.y, r.o.z, r.tminn); // read back by candidate resolution
 			}
@@ -354,28 +360,26 @@ __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScen
 		// ---- BM_WG_PERIOD phases per wave and redistribution: each time whichever the majority of its live lanes wants
 #pragma unroll 1
 		for (int ph = 0; ph < BM_WG_PERIOD; ++ph) {
-			const int nAw = __popcll(__ballot(state == ST_OUTER)), nBw = __popcll(__ballot(state == ST_CAND));
+			const int nJw = __popcll(__ballot(state == ST_JUMP));
+			const int nAw = __popcll(__ballot(state == ST_OUTER)) + nJw, nBw = __popcll(__ballot(state == ST_CAND));
 			if (nBw > 0 && (nBw >= BM_WG_CAND_MIN || nBw >= nAw)) {
 				if (DBG && lane == 0) { runsB++; lanesB += nBw; }
 				if (state == ST_CAND) {
-					// what only this phase reads is not carried through the pool: the block record (mask, arena base),
-					// the ray's origin in brick units and entry distance (scratch record), its direction (queue record)
-					load_block(sc, r);
+					// what only this phase reads is not carried through the pool: the ray's origin in brick units and entry
+					// distance (scratch record), its direction (queue record)
 					const float4 c = cold[idx];
 					const float* q = CONNECT ? reinterpret_cast<const float*>(shadow + idx) : reinterpret_cast<const float*>(work + idx);
 					r.o = mk(c.x, c.y, c.z);
 					r.tminn = c.w;
 					r.d = mk(q[3], q[4], q[5]);
-					state = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick);
+					state = process_candidate<DBG, 1>(sc, fc.campos, r, info, tally, lds_brick);
 					if (state == ST_NEED) ended = true;
 				}
 			} else if (nAw > 0) {
-				const bool walking = state == ST_OUTER;
-#pragma unroll 1
-				for (int k = 0; k < BM_WG_STEPS; ++k) {
-					if (DBG) { const int n = __popcll(__ballot(state == ST_OUTER)); if (lane == 0) { runsA++; lanesA += n; } }
-					if (state == ST_OUTER) state = outer_step<DBG>(sc, r, tally);
-				}
+				const bool walking = state == ST_OUTER || state == ST_JUMP;
+				uint32_t ra = 0, la = 0;
+				state = walk_round<DBG, BM_WG_STEPS>(sc, r, state, nJw, nAw - nJw, tally, ra, la);
+				if (DBG && lane == 0) { runsA += ra; lanesA += la; }
 				if (walking && state == ST_NEED) ended = true; // left the grid
 			}
 		}

@@ -107,6 +107,17 @@ def local_rows(params: FrameParams) -> int:
     return int(_lib.load().bm_local_rows(C.byref(p)))
 
 
+def host_cube_field(grid_size, grid_height):
+    """The octant cube field of the generated world (bm_host_cube_field): uint8 [8, cells_height+2, cells+2, cells+2]."""
+    L = _lib.load()
+    n = C.c_size_t(0)
+    check(L.bm_host_cube_field(grid_size, grid_height, None, 0, C.byref(n)))
+    out = np.zeros(n.value, np.uint8)
+    check(L.bm_host_cube_field(grid_size, grid_height, out.ctypes.data, out.size, C.byref(n)))
+    cx, cz = grid_size // 8 + 2, grid_height // 8 + 2
+    return out.reshape(8, cz, cx, cx)
+
+
 def host_column_heights(grid_size, grid_height, sx, sy):
     """Terrain heights of one supercell column from the product's CPU generator (no device needed)."""
     out = np.zeros((128, 128), np.float32)

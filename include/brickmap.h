@@ -38,6 +38,9 @@ extern "C" {
 /* frame flags */
 #define BM_FLAG_PRIMARY_ONLY 1u /* BASELINE config 1: extend the primary ray only          */
 #define BM_FLAG_COUNTERS 2u     /* accumulate the traversal counters (instrumented kernel)  */
+#define BM_FLAG_SAMPLE_ITEMS 4u /* schedule (4x4 chunk, sample) work items instead of pixels: samples of a pixel run on
+                                   different lanes and are summed with float atomics (order not fixed; no debug_dev).
+                                   For shards with few pixels and many samples, e.g. 1/N row bands of a multi-GPU frame */
 
 typedef struct bm_scene bm_scene; /* Scene + its GPUScene view (Scene.h:7-44), one GPU */
 
@@ -146,6 +149,14 @@ BM_API int bm_host_column_heights(int grid_size, int grid_height, int sx, int sy
 BM_API int bm_host_generate_supercell(int grid_size, int grid_height, int sx, int sy, int sz, uint32_t* indices4096,
                                       uint32_t* brick_count, uint32_t* bricks, uint32_t brick_capacity);
 
+/* The octant cube field the GPU walk reads instead of index words while it crosses empty space (no reference
+ * counterpart: the reference loads one index word per visited cell, voxel.cuh:192-200).  8 planes of
+ * (cells+2)^2 x (cells_height+2) bytes, x fastest, one border cell all round; plane o (bit 0 / 1 / 2 = direction
+ * negative in x / y / z), cell c: edge (<= 254) of the largest cube of empty brick cells inside the grid with c as
+ * its near corner, 0 = the cell holds a brick, 255 = border.  Builds the world on the host; *bytes = size needed
+ * (call with field = NULL to query). */
+BM_API int bm_host_cube_field(int grid_size, int grid_height, uint8_t* field, size_t capacity, size_t* bytes);
+
 /* ---- State (state.h:5-34): the accumulation ("blit") buffer lives in device memory the
  * caller owns; these helpers exist for callers without their own allocator. */
 BM_API int bm_buffer_alloc(int device, size_t bytes, void** dev_ptr);
@@ -161,7 +172,13 @@ BM_API int bm_local_rows(const bm_frame_params* params);
  * radiance, a = number of terminated paths; state.h:22, kernel.cu:301,319-322,341-343).
  * debug_dev: NULL or 8 uint32 per pixel (hit records).  hip_stream: the hipStream_t to
  * launch on, used as given (NULL = the device's default stream, like the reference's <<<>>> launches).
- * Asynchronous with respect to the host. */
+ * Asynchronous with respect to the host.
+ * Memory and ordering contract: accum_dev (and debug_dev) must be ordinary coarse-grained device memory
+ * (hipMalloc / bm_buffer_alloc / a torch CUDA tensor): the wavefront mode accumulates with hardware float
+ * atomics, which are not defined on fine-grained or host-mapped allocations.  A scene is not thread-safe, and
+ * all frames of one scene must be issued on ONE stream at a time (each launch resets the scene's ticket
+ * counters and updates accum_dev without atomics): wait for a frame before issuing the next one on a
+ * different stream.  Width and height are limited to 65535, a shard to 2^32 pixels. */
 BM_API int bm_render_frame(bm_scene* scene, const bm_camera* camera, const bm_frame_params* params,
                            float* accum_dev, uint32_t* debug_dev, void* hip_stream);
 /* blit_onto_framebuffer (kernel.cu:348-364) into an offscreen float4 buffer: rgb/a, a=1, gamma 1/2.2 */

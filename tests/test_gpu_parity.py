@@ -29,13 +29,26 @@ def assert_radiance(got, want):
     assert float(err.max()) <= RTOL, f"max relative radiance error {err.max():.3e}"
 
 
-def gpu_render(bm, torch, scene, cam, params, accum=None, want_dbg=True):
+def gpu_render(bm, torch, scene, cam, params, accum=None, want_dbg=True, also_plain=True):
+    """Render through the C-ABI.  With want_dbg the instrumented instantiation trace_paths<true> runs (hit records for the
+    oracle comparison); the SAME frame is then rendered again with the production instantiation trace_paths<false> (the
+    one bench.py times: no hit records, no counters, twice the occupancy) and must give a bit-identical accumulator --
+    so every case that checks the instrumented kernel against the oracle also pins the benchmarked one."""
     rows = bm.local_rows(params)
     if accum is None:
         accum = torch.zeros((rows, params.width, 4), dtype=torch.float32, device="cuda:0")
+    before = accum.clone() if (want_dbg and also_plain) else None
     dbg = torch.zeros((rows, params.width, 8), dtype=torch.int32, device="cuda:0") if want_dbg else None
     scene.render(cam, params, accum, debug=dbg)
     torch.cuda.synchronize()
+    if before is not None:
+        import copy
+        plain = copy.copy(params)
+        plain.flags = params.flags & ~bm.BM_FLAG_COUNTERS
+        scene.render(cam, plain, before)
+        torch.cuda.synchronize()
+        a, b = accum.cpu().numpy(), before.cpu().numpy()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "trace_paths<false> differs from trace_paths<true>"
     return accum.cpu().numpy(), (dbg.cpu().numpy().view(np.uint32) if want_dbg else None)
 
 
@@ -591,3 +604,24 @@ def test_reference_flythrough_views_on_native_world(bm, orc, torch_cuda):
         assert_radiance(acc[rows], oacc[rows])
         assert np.count_nonzero(dbg[..., 1]) > 0  # the world is in view
     scene.close()
+
+
+def test_sample_items_mode_matches_pixel_items(bm, orc, torch_cuda, scene256):
+    """BM_FLAG_SAMPLE_ITEMS only changes how work is dealt out ((4x4 chunk, sample) items, float atomics): every sample is
+    the same path, so path counts are exact and radiance differs by summation order only."""
+    cam, _ = cameras(bm, orc, 256)
+    for kw in (dict(spp=5, sample_base=3), dict(spp=3, band_rows=16, shard_rank=1, shard_count=2), dict(spp=1)):
+        p = bm.FrameParams(150, 90, max_bounces=3, **kw)
+        want, _ = gpu_render(bm, torch_cuda, scene256, cam, p, want_dbg=False)
+        pi = bm.FrameParams(150, 90, max_bounces=3, flags=bm.BM_FLAG_SAMPLE_ITEMS, **kw)
+        got, _ = gpu_render(bm, torch_cuda, scene256, cam, pi, want_dbg=False)
+        assert np.array_equal(got[..., 3], want[..., 3])  # terminated paths per pixel: small integers, exact in any order
+        np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=2e-6, atol=1e-9)
+    # accumulates onto existing content like the default mode
+    acc = torch_cuda.full((90, 150, 4), 2.0, dtype=torch_cuda.float32, device="cuda:0")
+    got, _ = gpu_render(bm, torch_cuda, scene256, cam, bm.FrameParams(150, 90, spp=2, flags=bm.BM_FLAG_SAMPLE_ITEMS), accum=acc, want_dbg=False)
+    want, _ = gpu_render(bm, torch_cuda, scene256, cam, bm.FrameParams(150, 90, spp=2), accum=torch_cuda.full((90, 150, 4), 2.0, dtype=torch_cuda.float32, device="cuda:0"), want_dbg=False)
+    np.testing.assert_allclose(got, want, rtol=2e-6)
+    # hit records are per pixel: refused in this mode
+    with pytest.raises(bm.BrickmapError):
+        gpu_render(bm, torch_cuda, scene256, cam, bm.FrameParams(32, 32, spp=2, flags=bm.BM_FLAG_SAMPLE_ITEMS), want_dbg=True, also_plain=False)
