@@ -3,21 +3,25 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one launch of the path-trace kernel over the workload's frame: `spp` complete paths
-(primary + up to max_bounces bounces, one shadow ray per hit) for every pixel of this rank's rows,
-with the scene already resident in HBM.  N = 1 runs BASELINE.json configs[1]:
-1920x1080, 1 spp, 4-bounce (MAX_BOUNCES = 3 -> 4 segments), 8x8x8 superchunks, all bricks resident.
-N > 1 keeps the per-GPU work fixed (weak scaling) by sharding the SAMPLES: every rank traces the full frame with its
-own `spp` sample indices of each pixel (N*spp samples per pixel and step in total), then the N float4 frames are
-summed onto rank 0 over RCCL (brickmap_amd/dist.py FrameReducer); the reduction of frame i overlaps the tracing of
-frame i+1 and every reduction, including the last one, completes inside the timed region.  (Sharding the pixels
-instead -- row bands + gather, also in dist.py -- gives a bit-identical image but leaves each rank N*spp samples on
-1/N of the rows, a launch shape that costs the persistent kernel 1.2x / 1.5x / 2.5x at N = 2 / 4 / 8.)
+A "step" is one launch of the path-trace kernel over this rank's shard of the workload's frame: `spp` complete paths
+(primary + up to max_bounces bounces, one shadow ray per hit) for every pixel of the shard, scene resident in HBM.
+
+N = 1 runs BASELINE.json configs[1] itself: 1920x1080, 1 spp, 4-bounce (MAX_BOUNCES = 3 -> 4 segments), 8x8x8
+superchunks, all bricks resident.
+
+N > 1 STRONG-scales one fixed job with the north-star decomposition: the same 1080p / 4-segment frame at
+MULTI_GPU_SPP = 8 samples per pixel, cut into interleaved 16-row bands (band b belongs to rank b % N); every rank traces
+all 8 samples of its rows into a packed float4 buffer (work items = (4x4 chunk, sample) pairs, BM_FLAG_SAMPLE_ITEMS, so
+the persistent waves stay fed on 1/N of the pixels), and the packed bands are gathered to rank 0 over RCCL/xGMI
+(brickmap_amd/dist.py FrameGatherer: grouped send/recv, 33 MB / N per peer per step).  The gather of step i overlaps the
+tracing of step i+1; every gather, including the last, completes inside the timed region.  Rates are per nominal ray,
+so the N = 1 line (1 spp) and the N > 1 lines (8 spp over N ranks) are directly comparable.
+`--decomposition samples` keeps the alternative cut (every rank the full frame with its own samples, ONE sum-reduction
+after the last step -- the buffers are additive), `--scaling weak` makes the job grow with N (N spp in total).
 
 metric: Mrays/s = width * height * spp_total * segments / seconds  (nominal rays).
-The line also carries `roofline` (algorithmic bytes of the kernel / its HIP-event duration against
-the 8 TB/s HBM peak) and, on rank 0 at N = 1, `cpu_baseline` (the oracle's scalar C port of the same
-path timed on the host cores).
+The line also carries `roofline` (algorithmic bytes of the kernel / its HIP-event duration against the 8 TB/s HBM
+peak) and, on rank 0 at N = 1, `cpu_baseline` (the oracle's scalar C port of the same path timed on the host cores).
 """
 import argparse
 import json
@@ -30,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+PROFILE_ROUND = "r02"  # profiles/<round>_pmc_summary*.json is where roofline.traffic comes from
 
 
 def workload(name):
@@ -54,6 +59,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decomposition", choices=["rows", "samples"], default="rows",
+                    help="N > 1: rows = interleaved row bands + RCCL gather (north-star); samples = full frame per rank, one sum-reduction at the end")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = the fixed job (frame at --multi-gpu-spp samples) over N ranks; weak = N x spp samples in total")
+    ap.add_argument("--multi-gpu-spp", type=int, default=8, help="samples per pixel of the strong-scaled job (N > 1)")
+    ap.add_argument("--streaming-mode", choices=["overlapped", "blocking"], default="overlapped",
+                    help="streaming workloads: overlapped = two request rings, the host never waits for the GPU; blocking = the reference's order")
     ap.add_argument("--schedule", choices=["fused", "wavefront"], default="fused",
                     help="fused = one persistent kernel tracing complete paths (the product's default); wavefront = the "
                          "reference's own queue schedule, one segment of every path in flight per step (N = 1 only)")
@@ -87,7 +99,18 @@ def main():
     W, H, spp, max_bounces, n_super, streaming = workload(args.workload)
     G = 128 * n_super
     segments = max_bounces + 1
-    spp_step = spp * world  # weak scaling: N x the samples per pixel and step, each rank the full frame with its own sample slice
+    by_rows = world > 1 and args.decomposition == "rows"
+    # samples per pixel of one whole-job step, and of this rank's launch
+    if world == 1:
+        spp_total = spp
+    elif args.scaling == "strong":
+        spp_total = max(args.multi_gpu_spp, 1) if args.workload == "config2" else spp * 8  # configs 4 / 5 name their totals (2 x 8, 4 x 8)
+    else:
+        spp_total = spp * world
+    if world > 1 and not by_rows and spp_total % world:
+        raise SystemExit(f"--decomposition samples needs spp_total ({spp_total}) divisible by the number of ranks")
+    spp_rank = spp_total if (by_rows or world == 1) else spp_total // world
+    band = bm.dist.DEFAULT_BAND_ROWS
 
     # ---- scene replica on this GPU (world build is CPU plumbing and is not timed)
     t0 = time.time()
@@ -95,22 +118,34 @@ def main():
     if streaming:
         scene.set_queue_capacity(1 << 20)
         scene.reset_residency()
+        scene.set_streaming_mode(args.streaming_mode == "overlapped")
     else:
         scene.preload_all()
     build_s = time.time() - t0
     cam = bm.Camera(position=(G / 2, G / 8, 0.8 * G), horizontal_angle=0.8, vertical_angle=-0.5).update()
-    state = bm.State(W, H, device=local_rank)
+    if by_rows:
+        state = bm.State(W, H, device=local_rank, band_rows=band, shard_rank=rank, shard_count=world)
+    else:
+        state = bm.State(W, H, device=local_rank)
     accum = state.blit_buffer
     if args.schedule == "wavefront":
         if world != 1:
             raise SystemExit("--schedule wavefront does not shard (replicas only): run it with --gpus 1")
         return bench_wavefront(args, bm, torch, np, scene, cam, accum, W, H, max_bounces, n_super, G, streaming, build_s)
 
-    def params(step, flags=0):  # rank r owns samples [step*N*spp + r*spp, ... + spp) of every pixel
-        return bm.FrameParams(W, H, spp=spp, sample_base=(step * world + rank) * spp, max_bounces=max_bounces, flags=flags)
+    item_flag = bm.BM_FLAG_SAMPLE_ITEMS if world > 1 else 0  # (chunk, sample) work items keep 1/N-of-the-pixels shards fed
 
-    # N > 1: the reduction of frame i runs on RCCL's stream while frame i+1 is being traced (one reduction in flight)
-    gatherer = bm.dist.FrameReducer(H, W, device=dev) if world > 1 else None
+    def params(step, flags=0):
+        if by_rows:  # rank r owns the bands b with b % N == r and traces every sample of the step for them
+            return bm.FrameParams(W, H, spp=spp_rank, sample_base=step * spp_total, max_bounces=max_bounces, flags=flags | item_flag,
+                                  band_rows=band, shard_rank=rank, shard_count=world)
+        # sample shards: rank r owns samples [step*spp_total + r*spp_rank, ... + spp_rank) of every pixel
+        return bm.FrameParams(W, H, spp=spp_rank, sample_base=step * spp_total + rank * spp_rank, max_bounces=max_bounces, flags=flags | item_flag)
+
+    # rows: the gather of frame i runs on RCCL's stream while frame i+1 is being traced (one gather in flight);
+    # samples: ONE sum-reduction after the last step (the per-rank buffers are additive)
+    gatherer = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev) if by_rows else None
+    reducer = bm.dist.FrameReducer(H, W, device=dev) if (world > 1 and not by_rows) else None
 
     def one_step(step):
         scene.render(cam, params(step), accum)
@@ -118,13 +153,13 @@ def main():
             scene.process_load_queue()
         if gatherer is not None:
             gatherer.finish()      # frame step-1 is complete on rank 0
-            gatherer.start(accum)  # snapshot + asynchronous sum-reduction of this frame
+            gatherer.start(accum)  # snapshot + asynchronous gather of this frame's packed bands
         return accum
 
     if streaming:  # reach streaming steady state before anything is timed
         for i in range(64):
             scene.render(cam, params(0), accum)
-            if scene.process_load_queue() == 0:
+            if scene.process_load_queue() == 0 and i > 2:
                 break
         accum.zero_()
 
@@ -140,7 +175,10 @@ def main():
     for i in range(args.steps):
         one_step(args.warmup + i)
     if gatherer is not None:
-        gatherer.finish()  # the last frame's reduction is inside the timed region
+        gatherer.finish()  # the last frame's gather is inside the timed region
+    if reducer is not None:
+        reducer.start(accum)
+        reducer.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -164,7 +202,7 @@ def main():
     achieved_gbs = alg_bytes / args.steps / avg_kernel_s / 1e9
     actual_rays = cnt["extend_rays"] + cnt["shadow_rays"]
 
-    nominal_rays_per_step = W * H * spp_step * segments
+    nominal_rays_per_step = W * H * spp_total * segments
     value = nominal_rays_per_step * args.steps / elapsed / 1e6
 
     if rank != 0:
@@ -181,16 +219,21 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling if world > 1 else "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (SimplexNoise terrain built on the CPU by the product generator; canonical xorshift RNG streams)",
         "config": {
-            "workload": f"BASELINE {args.workload}: {W}x{H}, {spp} spp per GPU-step (x{world} ranks = {spp_step} spp), "
+            "workload": f"BASELINE {args.workload}: {W}x{H}, {spp_total} spp per step, "
                         f"{segments} segments/path, {n_super}^3 superchunks ({G}^3 voxels), "
-                        + ("brick streaming at steady state" if streaming else "all bricks pre-loaded"),
-            "width": W, "height": H, "spp_per_step": spp_step, "segments": segments, "world_voxels": G,
-            "sharding": f"{world} x sample shards (every rank the full frame, its own {spp} of the {spp_step} samples) + RCCL sum-reduce to rank 0" if world > 1 else "single GPU",
+                        + (f"brick streaming at steady state ({args.streaming_mode})" if streaming else "all bricks pre-loaded")
+                        + ("" if world == 1 else f"; the fixed {spp_total}-spp job strong-scaled over {world} ranks" if args.scaling == "strong"
+                           else f"; weak scaling, {spp_total // world} spp per rank"),
+            "width": W, "height": H, "spp_per_step": spp_total, "segments": segments, "world_voxels": G,
+            "sharding": ("single GPU" if world == 1 else
+                         f"{world} x interleaved {band}-row bands, every rank all {spp_rank} samples of its rows ((chunk, sample) work items) "
+                         f"+ RCCL gather of the packed bands to rank 0, one gather in flight" if by_rows else
+                         f"{world} x sample shards (every rank the full frame, {spp_rank} of the {spp_total} samples) + one RCCL sum-reduce to rank 0 after the last step"),
             "camera": {"position": list(cam.position), "angles": [0.8, -0.5]},
             "world_build_s": round(build_s, 2),
         },
@@ -202,7 +245,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
-            "traffic": pmc_traffic(args.workload),
+            **pmc_traffic(args.workload),
             "kernel": "bm::trace_paths<false>",
             "kernel_ms_avg": round(float(np.mean(kernel_ms)), 4),
             "algorithmic_bytes_per_launch": alg_bytes / args.steps,
@@ -212,7 +255,7 @@ def main():
     }
 
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(W, H, spp, max_bounces, G, cam)
+        out["cpu_baseline"] = cpu_baseline(W, H, max_bounces, G, cam)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -289,44 +332,80 @@ def bench_wavefront(args, bm, torch, np, scene, cam, accum, W, H, max_bounces, n
     print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(W, H, spp, max_bounces, G, cam):
-    """The oracle's scalar C port of the same per-pixel path (oracle/oracle.c orc_render) on all host cores.
-    Sample: whole frames of the same workload -- one calibration frame, then enough samples per pixel for
-    roughly 3 s of wall time (tens of CPU-seconds on a many-core host)."""
+def host_cpu():
+    """(model name, physical cores, logical CPUs) of this host, from /proc/cpuinfo."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, (len(cores) or logical), logical
+
+
+def cpu_baseline(W, H, max_bounces, G, cam):
+    """The oracle's scalar C port of the same per-pixel path (oracle/oracle.c orc_render), timed on the host: one thread
+    per PHYSICAL core (tile-granular dynamic scheduling), plus a 1-thread figure.
+    Sample: whole frames of the same workload -- one calibration frame, then enough samples per pixel for roughly 3 s of
+    wall time on all cores; 1 thread: every 8th 8-row band of one frame (an eighth of the pixels, spread over the image)."""
     import oracle
-    cores = os.cpu_count() or 1
-    world = oracle.World(G, G, threads=cores)
+    model, physical, logical = host_cpu()
+    threads = max(1, min(physical, 256))
+    world = oracle.World(G, G, threads=logical)
     world.reset_device(True)
     ocam = oracle.make_camera(cam.position, cam.direction)
-    _, _, _, t1 = world.render(ocam, oracle.make_frame(W, H, spp=1, max_bounces=max_bounces), want_dbg=False, threads=cores)
+    _, _, _, t1 = world.render(ocam, oracle.make_frame(W, H, spp=1, max_bounces=max_bounces), want_dbg=False, threads=threads)
     n = max(1, min(64, int(3.0 / max(t1, 1e-3))))
-    _, _, cnt, secs = world.render(ocam, oracle.make_frame(W, H, spp=n, max_bounces=max_bounces, sample_base=1), want_dbg=False, threads=cores)
+    _, _, cnt, secs = world.render(ocam, oracle.make_frame(W, H, spp=n, max_bounces=max_bounces, sample_base=1), want_dbg=False, threads=threads)
     nominal = W * H * n * (max_bounces + 1)
+    strip = oracle.make_frame(W, H, spp=1, max_bounces=max_bounces, band_rows=8, shard_rank=0, shard_count=8)
+    strip_rows = sum(1 for y in range(H) if (y // 8) % 8 == 0)
+    _, _, cnt1, secs1 = world.render(ocam, strip, want_dbg=False, threads=1)
+    nominal1 = W * strip_rows * (max_bounces + 1)
     return {
         "value": round(nominal / secs / 1e6, 4),
         "unit": "Mrays/s",
-        "cores": cores,
+        "cores": threads,
         "kind": "port",
         "sample": f"{n} samples/pixel of the same {W}x{H} frame ({nominal} nominal rays, "
-                  f"{cnt['extend_rays'] + cnt['shadow_rays']} actual) in {secs:.2f} s on {cores} threads",
+                  f"{cnt['extend_rays'] + cnt['shadow_rays']} actual) in {secs:.2f} s on {threads} threads (one per physical core)",
+        "cpu_model": model, "physical_cores": physical, "logical_cpus": logical,
+        "one_thread": {"value": round(nominal1 / secs1 / 1e6, 4), "unit": "Mrays/s",
+                       "sample": f"every 8th 8-row band of one frame ({nominal1} nominal rays, {cnt1['extend_rays'] + cnt1['shadow_rays']} actual) in {secs1:.2f} s"},
     }
 
 
 def pmc_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary of this workload (separate --pmc passes,
-    tools/pmc.sh), or None.  Units and correction as MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and
-    WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, i.e. reports half of a 16 B/lane
-    stream, so it is doubled (this kernel's traffic is dominated by the 16-byte brick / mask-record reads);
-    WRITE_SIZE is taken as reported (uncalibrated per the guide)."""
-    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    """{"traffic": HBM bytes per launch, "traffic_source": where it comes from}.  The counters are NOT collected by this
+    run (rocprofv3 PMC needs its own passes, tools/pmc.sh): the figure is read from the committed summary of the same
+    workload and kernel, and the source is named in the line.  Units and correction as MI355X_MICROARCH.md (HBM section)
+    prescribes: FETCH_SIZE and WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, i.e.
+    reports half of a 16 B/lane stream, so it is doubled; WRITE_SIZE is taken as reported (uncalibrated per the guide)."""
+    name = "pmc_summary.json" if workload == "config2" else f"pmc_summary_{workload}.json"
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_" + name)
     try:
         with open(path) as f:
             d = json.load(f)
         if d.get("workload") != workload:
-            return None
-        return int((2.0 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024)
+            return {"traffic": None, "traffic_source": None}
+        return {"traffic": int((2.0 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024),
+                "traffic_source": f"profiles/{os.path.basename(path)} (separate rocprofv3 --pmc passes of this workload, not this run)"}
     except (OSError, KeyError, ValueError):
-        return None
+        return {"traffic": None, "traffic_source": None}
 
 
 if __name__ == "__main__":

@@ -1051,6 +1051,10 @@ static void render_pixel(render_job* job, const cam_basis* cb, const orc_sky_sta
 	}
 }
 
+/* Work is handed out in tiles of 64 x 8 pixels (a row-granular queue leaves most of a many-core host idle at the end of
+ * the frame: 1080 rows over 256 threads, and a terrain row costs several times a sky row). */
+#define ORC_TILE_W 64
+#define ORC_TILE_H 8
 static void* render_worker(void* arg) {
 	render_job* job = (render_job*)arg;
 	const orc_frame* f = job->f;
@@ -1058,11 +1062,15 @@ static void* render_worker(void* arg) {
 	camera_basis(job->cam, f->width, f->height, &cb);
 	orc_sky_state sky;
 	sky_state_init(&sky, f->sun_x, f->sun_y);
+	const int tiles_x = (f->width + ORC_TILE_W - 1) / ORC_TILE_W, tiles_y = (f->height + ORC_TILE_H - 1) / ORC_TILE_H;
 	for (;;) {
-		int y = __atomic_fetch_add(job->next_row, 1, __ATOMIC_RELAXED);
-		if (y >= f->height) break;
-		if (!row_in_shard(f, y)) continue;
-		for (int x = 0; x < f->width; x++) render_pixel(job, &cb, &sky, (unsigned)x, (unsigned)y);
+		int t = __atomic_fetch_add(job->next_row, 1, __ATOMIC_RELAXED);
+		if (t >= tiles_x * tiles_y) break;
+		const int x0 = (t % tiles_x) * ORC_TILE_W, y0 = (t / tiles_x) * ORC_TILE_H;
+		for (int y = y0; y < y0 + ORC_TILE_H && y < f->height; y++) {
+			if (!row_in_shard(f, y)) continue;
+			for (int x = x0; x < x0 + ORC_TILE_W && x < f->width; x++) render_pixel(job, &cb, &sky, (unsigned)x, (unsigned)y);
+		}
 	}
 	return NULL;
 }
