@@ -114,9 +114,11 @@ def main():
 
     # ---- scene replica on this GPU (world build is CPU plumbing and is not timed)
     t0 = time.time()
-    scene = bm.Scene(G, G, device=local_rank).generate()
+    scene = bm.Scene(G, G, device=local_rank)
     if streaming:
         scene.set_queue_capacity(1 << 20)
+    scene.generate()
+    if streaming:
         scene.reset_residency()
         scene.set_streaming_mode(args.streaming_mode == "overlapped")
     else:

@@ -43,7 +43,8 @@ class bm_scene_info(C.Structure):
                 ("lod_distance_8x8x8", C.c_int32), ("lod_distance_2x2x2", C.c_int32),
                 ("generated", C.c_int32), ("on_device", C.c_int32),
                 ("total_bricks", C.c_uint64), ("resident_bricks", C.c_uint64),
-                ("index_bytes", C.c_uint64), ("brick_bytes", C.c_uint64)]
+                ("index_bytes", C.c_uint64), ("brick_bytes", C.c_uint64),
+                ("pool_bytes", C.c_uint64), ("cube_field_bytes", C.c_uint64)]
 
 
 COUNTER_NAMES = ("index_loads", "brick_tests", "byte_tests", "voxel_steps", "extend_rays",

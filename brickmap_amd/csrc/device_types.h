@@ -7,51 +7,21 @@ namespace bm {
 // Device view of the scene (the reference passes Scene::GPUScene by value, Scene.h:9-17).
 //
 // HBM layout (DESIGN.md "Data layout"):
-//   index_grid  u32[supercells * 4096]   supercell-major; supercell id = sx + sy*sg_xy + sz*sg_xy^2,
-//                                         word (lx + 16*ly + 256*lz) inside it  -- the reference's
-//                                         addressing (voxel.cuh:197-198) minus its pointer table
-//   super_info  16 B per supercell        {u64 coarse, u32 brick_base, u32 0}: brick_base = first arena slot of the
-//                                         supercell (exclusive prefix sum of non-empty brick counts; replaces
-//                                         Brick**), read by the upload kernel.  `coarse` (which of its 4x4x4
-//                                         blocks hold bricks) is no longer read by any kernel: the walk used it
-//                                         to skip the records of empty blocks until that turned out to cost more
-//                                         instructions than the loads it saved.
-//   block_grid  16 B per 4x4x4-brick block {u64 mask, u32 base, u32 outside}, a dense x-fastest 3-D array over the
-//                                         whole grid plus a one-block border: mask bit (cx + 4*cy + 16*cz) =
-//                                         "index word of that brick is non-zero".  Static (residency flags never
-//                                         make a word zero), so the DDA can skip the index load of empty
-//                                         cells while still performing the reference's per-cell arithmetic.
-//                                         base = arena slot of the block's first brick: bricks are stored
-//                                         block by block in mask-bit order, so a brick's slot is
-//                                         base + popcount(mask below its bit) -- known before (and fetched
-//                                         in parallel with) its index word.  Border blocks have outside = 1:
-//                                         a ray that steps off the grid reads one, which IS the reference's
-//                                         per-step exit test (voxel.cuh:256) -- the walk needs no bounds
-//                                         compare, no supercell bookkeeping and one independent 16-byte load
-//                                         per move (re-read every step; consecutive reads are L1 hits).
-//   brick_arena 64 B * total_bricks      exact-fit pool, every brick has a fixed home slot; the 12-bit slot of
-//                                         a device index word is that slot relative to brick_base
+//   index_grid  u32[supercells * 4096]   the reference's index words (variables.h:29-33), supercell-major; supercell id =
+//                                         sx + sy*sg_xy + sz*sg_xy^2, word (lx + 16*ly + 256*lz) inside it -- the
+//                                         reference's addressing (voxel.cuh:197-198) minus its pointer table
+//   pool_base   u32[supercells]          first arena slot of each supercell's brick pool (replaces Brick** bricks,
+//                                         Scene.h:11): a brick lives at arena slot pool_base[sc] + (word & 0xFFF), the
+//                                         12-bit slot the index word carries, exactly as voxel.cuh:222 addresses it.
+//                                         Pools start at 16 bricks and double (Scene.cpp:231-251); a grown pool moves to
+//                                         a new region of the arena and its entry here is rewritten.
+//   brick_arena 64 B * arena capacity    one allocation that all pools live in (power-of-two regions, free lists per
+//                                         size; grows by residency, not by world size)
+//   cube_field  8 planes, 1 B per cell   octant cube field (below): what the walk reads while it crosses empty space
 //   load_queue  int3[queue_cap] + count  brick-request ring (voxel.cuh:228-245)
-struct SuperInfo {
-	unsigned long long coarse;
-	uint32_t brick_base;
-	uint32_t reserved;
-};
-static_assert(sizeof(SuperInfo) == 16, "one dwordx4 per supercell");
-
-struct BlockInfo {
-	unsigned long long mask;
-	uint32_t base;
-	uint32_t reserved;
-};
-static_assert(sizeof(BlockInfo) == 16, "one dwordx4 per block");
-
 struct DeviceScene {
 	uint32_t* index_grid;
-	const SuperInfo* super_info;
-	const BlockInfo* block_grid; // dense, bordered (see above); points 3 * (1 + bg_x + bg_xy) records BEFORE the array: the
-	                             // walk indexes it with block coordinates that carry the packed cell's bias (load_block)
-	int bg_x, bg_xy;             // row / slice pitch in blocks
+	const uint32_t* pool_base;
 	const uint32_t* brick_arena; // 16 words per brick
 	// octant cube field (traverse.h "cube-field walk"): 8 planes of one byte per cell of the grid plus a one-cell border,
 	// x-fastest; byte = edge of the largest empty cube with the cell as near corner along the plane's octant (bit 0 / 1 /
@@ -67,6 +37,11 @@ struct DeviceScene {
 	int sg_xy, sg_xy2;       // supercells per axis, squared
 	float grid_size_f, grid_height_f;
 	int lod_distance_8x8x8, lod_distance_2x2x2;
+};
+
+// a pool that has grown: `count` bricks move from arena slot `src` to `dst` (upload path, Scene.cpp:231-251)
+struct PoolMove {
+	uint32_t src, dst, count, supercell;
 };
 
 // Per-launch constants computed on the host (launch_kernels:371-403 and the view-independent

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <unordered_map>
 
 #include "kernels.h"
 
@@ -128,6 +129,8 @@ Scene::~Scene() {
 	if (ev_frame_done_) hipEventDestroy(ev_frame_done_);
 	if (h_bricks_) hipHostFree(h_bricks_);
 	if (h_indices_) hipHostFree(h_indices_);
+	if (h_moves_) hipHostFree(h_moves_);
+	if (d_moves_) hipFree(d_moves_);
 	if (d_bricks_queue_) hipFree(d_bricks_queue_);
 	if (d_indices_queue_) hipFree(d_indices_queue_);
 	if (d_counters_) hipFree(d_counters_);
@@ -205,6 +208,12 @@ int Scene::alloc_queue() {
 	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_indices_), n * sizeof(uint32_t), hipHostMallocDefault));  // Scene.cpp:32
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_bricks_queue_), n * sizeof(Brick)));                          // Scene.cpp:189
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_indices_queue_), n * sizeof(uint32_t)));                      // Scene.cpp:190
+	// a batch of n requests can make at most n pools grow
+	if (h_moves_) { hipHostFree(h_moves_); h_moves_ = nullptr; }
+	if (d_moves_) { hipFree(d_moves_); d_moves_ = nullptr; }
+	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_moves_), n * sizeof(PoolMove), hipHostMallocDefault));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_moves_), n * sizeof(PoolMove)));
+	moves_cap_ = static_cast<uint32_t>(n);
 	ring_cur_ = 0;
 	snapshot_pending_ = false;
 	view_.load_queue = d_load_queue_[0];
@@ -247,6 +256,9 @@ int Scene::set_lod(int lod8, int lod2) {
 
 int Scene::set_queue_capacity(int cap) {
 	if (cap <= 0) { set_error("queue capacity must be positive"); return BM_EINVAL; }
+	// resizing the ring drops what it holds while the REQUESTED bits of those bricks stay set (they would never be asked
+	// for again): the capacity belongs to the scene's construction, like the reference's constexpr (variables.h:35)
+	if (on_device_) { set_error("set the queue capacity before bm_scene_generate"); return BM_ESTATE; }
 	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipDeviceSynchronize());
 	queue_cap_ = cap;
@@ -255,61 +267,88 @@ int Scene::set_queue_capacity(int cap) {
 
 void Scene::free_device() {
 	if (d_index_grid_) hipFree(d_index_grid_);
-	if (d_super_info_) hipFree(d_super_info_);
-	if (d_block_grid_) hipFree(d_block_grid_);
+	if (d_pool_base_) hipFree(d_pool_base_);
 	if (d_arena_) hipFree(d_arena_);
 	if (d_cube_field_) hipFree(d_cube_field_);
 	d_cube_field_ = nullptr;
-	d_index_grid_ = d_arena_ = nullptr;
-	d_super_info_ = nullptr;
-	d_block_grid_ = nullptr;
+	d_index_grid_ = d_arena_ = d_pool_base_ = nullptr;
+	arena_capacity_ = arena_top_ = pool_bricks_ = 0;
 	on_device_ = false;
 }
 
-// device half of Scene::generate (Scene.cpp:152-190): one flat index grid + one exact-fit brick arena
-// instead of 2 x supercells cudaMallocs and two pointer tables.
+// ---------------------------------------------------------------- brick arena
+void Scene::arena_reset() {
+	arena_top_ = 0;
+	pool_bricks_ = 0;
+	for (auto& f : free_regions_) f.clear();
+	freed_this_batch_.clear();
+}
+
+// Grow the arena to at least `bricks` (doubling), keeping what it holds.  Synchronises the device: frames in flight may
+// still read the old allocation, and the copy must see every upload.  Rare: log2(resident bricks) times per scene.
+int Scene::arena_reserve(uint64_t bricks, bool exact) {
+	if (bricks <= arena_capacity_ && !(exact && arena_top_ == 0 && arena_capacity_ > 2 * std::max<uint64_t>(bricks, 1ull << 16))) return 0;
+	uint64_t cap = bricks;
+	if (!exact) { // growth by residency: double
+		cap = std::max<uint64_t>(arena_capacity_, 1ull << 16); // 4 MiB to start with
+		while (cap < bricks) cap *= 2;
+	} else if (arena_top_ == 0) {
+		cap = std::max<uint64_t>(bricks, 1ull << 16); // (re)sized for a known residency: exact fit, shrinking an oversized arena
+	}
+	if (cap >= (1ull << 32)) { set_error("brick arena would exceed 2^32 bricks"); return BM_EINVAL; }
+	BM_HIP(hipDeviceSynchronize());
+	uint32_t* fresh = nullptr;
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&fresh), cap * sizeof(Brick)));
+	if (d_arena_ && arena_top_ > 0) BM_HIP(hipMemcpy(fresh, d_arena_, arena_top_ * sizeof(Brick), hipMemcpyDeviceToDevice));
+	if (d_arena_) BM_HIP(hipFree(d_arena_));
+	d_arena_ = fresh;
+	arena_capacity_ = cap;
+	view_.brick_arena = d_arena_;
+	return 0;
+}
+
+// A region of `bricks` (a power of two >= kStartingPool) for one pool: from the free list of that size, else from the top.
+int Scene::region_alloc(uint32_t bricks, uint32_t* offset) {
+	int cls = 0;
+	while ((1u << cls) < bricks) ++cls;
+	if (!free_regions_[cls].empty()) {
+		*offset = free_regions_[cls].back();
+		free_regions_[cls].pop_back();
+	} else {
+		if (int e = arena_reserve(arena_top_ + bricks)) return e;
+		*offset = static_cast<uint32_t>(arena_top_);
+		arena_top_ += bricks;
+	}
+	pool_bricks_ += bricks;
+	return 0;
+}
+
+// A vacated region becomes reusable once the batch that vacates it has been queued: its move kernel still reads it, and
+// a pool growing in the SAME batch must not be given it (later batches are ordered behind this one on the load stream).
+void Scene::region_free_deferred(uint32_t bricks, uint32_t offset) {
+	int cls = 0;
+	while ((1u << cls) < bricks) ++cls;
+	freed_this_batch_.emplace_back(cls, offset);
+	pool_bricks_ -= bricks;
+}
+
+// device half of Scene::generate (Scene.cpp:152-190): one flat index grid, one pool-base word per supercell and one
+// brick arena instead of 2 x supercells cudaMallocs and two pointer tables; plus the octant cube field of the walk.
 int Scene::allocate_device() {
 	BM_HIP(hipSetDevice(device_));
 	free_device();
 	const WorldDims& d = world.dims;
-	brick_base_.assign(d.supercells, 0u);
 	uint64_t run = 0;
-	for (int i = 0; i < d.supercells; ++i) {
-		brick_base_[i] = static_cast<uint32_t>(run);
-		run += world.supercells[i].bricks.size();
-	}
+	for (int i = 0; i < d.supercells; ++i) run += world.supercells[i].bricks.size();
 	if (run >= (1ull << 32)) { set_error("world has more than 2^32 bricks"); return BM_EINVAL; }
 	total_bricks_ = run;
 	const size_t index_bytes = static_cast<size_t>(d.supercells) * kCellsPerSupercell * sizeof(uint32_t);
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_index_grid_), index_bytes));
-	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_super_info_), static_cast<size_t>(d.supercells) * sizeof(SuperInfo)));
-	// dense block grid with a one-block border of "outside" records (device_types.h)
-	const int nbx = d.cells / 4 + 2, nbz = d.cells_height / 4 + 2;
-	const size_t n_blocks = static_cast<size_t>(nbx) * nbx * nbz;
-	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_block_grid_), n_blocks * sizeof(BlockInfo)));
-	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_arena_), std::max<size_t>(64, static_cast<size_t>(total_bricks_) * sizeof(Brick))));
-	{
-		std::vector<SuperInfo> info(d.supercells);
-		std::vector<BlockInfo> blocks(n_blocks, BlockInfo{0ull, 0u, 1u}); // border: outside
-		for (int i = 0; i < d.supercells; ++i) {
-			const HostSupercell& c = world.supercells[i];
-			info[i] = SuperInfo{c.coarse_mask, brick_base_[i], 0u};
-			const int sx = i % d.supergrid_xy, sy = (i / d.supergrid_xy) % d.supergrid_xy, sz = i / (d.supergrid_xy * d.supergrid_xy);
-			for (int b = 0; b < 64; ++b) {
-				const int bx = sx * 4 + (b & 3), by = sy * 4 + ((b >> 2) & 3), bz = sz * 4 + (b >> 4);
-				blocks[(static_cast<size_t>(bz + 1) * nbx + (by + 1)) * nbx + (bx + 1)] = BlockInfo{c.fine_mask[b], brick_base_[i] + c.block_base[b], 0u};
-			}
-		}
-		BM_HIP(hipMemcpy(d_super_info_, info.data(), info.size() * sizeof(SuperInfo), hipMemcpyHostToDevice));
-		BM_HIP(hipMemcpy(d_block_grid_, blocks.data(), blocks.size() * sizeof(BlockInfo), hipMemcpyHostToDevice));
-	}
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_pool_base_), static_cast<size_t>(d.supercells) * sizeof(uint32_t)));
+	BM_HIP(hipMemset(d_pool_base_, 0, static_cast<size_t>(d.supercells) * sizeof(uint32_t)));
 	view_.index_grid = d_index_grid_;
-	view_.super_info = d_super_info_;
-	view_.block_grid = reinterpret_cast<const BlockInfo*>(reinterpret_cast<uintptr_t>(d_block_grid_) -
-														   static_cast<uintptr_t>(3) * (1 + nbx + nbx * nbx) * sizeof(BlockInfo));
-	view_.bg_x = nbx;
-	view_.bg_xy = nbx * nbx;
-	view_.brick_arena = d_arena_;
+	view_.pool_base = d_pool_base_;
+	view_.brick_arena = nullptr;
 	{ // octant cube field: what the walk reads instead of index words while it crosses empty space
 		std::vector<uint8_t> field;
 		world.build_cube_field(field, 8);
@@ -356,14 +395,28 @@ int Scene::reset_residency() {
 	BM_HIP(hipDeviceSynchronize());
 	const WorldDims& d = world.dims;
 	std::vector<uint32_t> words(static_cast<size_t>(d.supercells) * kCellsPerSupercell);
+	std::vector<uint32_t> bases(d.supercells, 0u);
+	// every supercell that holds bricks starts with a pool of kStartingPool bricks (Scene.cpp:157-175, variables.h:15)
+	arena_reset();
+	uint64_t initial = 0;
+	for (int i = 0; i < d.supercells; ++i) initial += world.supercells[i].bricks.empty() ? 0u : kStartingPool;
+	if (int e = arena_reserve(std::max<uint64_t>(initial, 1), true)) return e;
 	for (int i = 0; i < d.supercells; ++i) {
 		HostSupercell& c = world.supercells[i];
 		c.resident = 0;
+		c.pool_capacity = 0;
+		c.pool_base = 0;
+		if (!c.bricks.empty()) {
+			if (int e = region_alloc(kStartingPool, &c.pool_base)) return e;
+			c.pool_capacity = kStartingPool;
+		}
+		bases[i] = c.pool_base;
 		uint32_t* dst = &words[static_cast<size_t>(i) * kCellsPerSupercell];
 		for (int j = 0; j < kCellsPerSupercell; ++j)
 			dst[j] = (c.indices[j] & BM_BRICK_LOADED_BIT) ? (BM_BRICK_UNLOADED_BIT | (c.indices[j] & BM_BRICK_LOD_BITS)) : 0u;
 	}
 	BM_HIP(hipMemcpy(d_index_grid_, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	BM_HIP(hipMemcpy(d_pool_base_, bases.data(), bases.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	for (int r = 0; r < 2; ++r) BM_HIP(hipMemset(d_load_count_[r], 0, sizeof(uint32_t)));
 	ring_cur_ = 0;
 	snapshot_pending_ = false;
@@ -380,22 +433,24 @@ int Scene::preload_all() {
 	BM_HIP(hipDeviceSynchronize());
 	const WorldDims& d = world.dims;
 	std::vector<uint32_t> words(static_cast<size_t>(d.supercells) * kCellsPerSupercell);
-	std::vector<Brick> ordered;
+	std::vector<uint32_t> bases(d.supercells, 0u);
+	// "all bricks pre-loaded" (BASELINE configs 1-2): every pool is its supercell's full host brick vector, exact fit, and
+	// the device words are the host words (slot | loaded | lod, Scene.cpp:104)
+	arena_reset();
+	if (int e = arena_reserve(std::max<uint64_t>(total_bricks_, 1), true)) return e;
 	for (int i = 0; i < d.supercells; ++i) {
 		HostSupercell& c = world.supercells[i];
-		uint32_t* dst = &words[static_cast<size_t>(i) * kCellsPerSupercell];
-		for (int j = 0; j < kCellsPerSupercell; ++j) { // host word with the brick's home slot in the arena
-			const uint32_t w = c.indices[j];
-			dst[j] = w ? ((w & ~BM_BRICK_INDEX_BITS) | c.device_slot[w & BM_BRICK_INDEX_BITS]) : 0u;
-		}
+		c.pool_base = static_cast<uint32_t>(arena_top_);
+		c.pool_capacity = static_cast<uint32_t>(c.bricks.size());
+		arena_top_ += c.bricks.size();
+		bases[i] = c.pool_base;
+		std::memcpy(&words[static_cast<size_t>(i) * kCellsPerSupercell], c.indices.data(), kCellsPerSupercell * sizeof(uint32_t));
 		c.resident = static_cast<uint32_t>(c.bricks.size());
-		if (!c.bricks.empty()) {
-			ordered.resize(c.bricks.size());
-			for (size_t h = 0; h < c.bricks.size(); ++h) ordered[c.device_slot[h]] = c.bricks[h];
-			BM_HIP(hipMemcpy(d_arena_ + static_cast<size_t>(brick_base_[i]) * kBrickWords, ordered.data(), ordered.size() * sizeof(Brick),
-							 hipMemcpyHostToDevice));
-		}
+		if (!c.bricks.empty())
+			BM_HIP(hipMemcpy(d_arena_ + static_cast<size_t>(c.pool_base) * kBrickWords, c.bricks.data(), c.bricks.size() * sizeof(Brick), hipMemcpyHostToDevice));
 	}
+	pool_bricks_ = total_bricks_;
+	BM_HIP(hipMemcpy(d_pool_base_, bases.data(), bases.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	BM_HIP(hipMemcpyAsync(d_index_grid_, words.data(), words.size() * sizeof(uint32_t), hipMemcpyHostToDevice, load_stream_));
 	for (int r = 0; r < 2; ++r) BM_HIP(hipMemsetAsync(d_load_count_[r], 0, sizeof(uint32_t), load_stream_));
 	BM_HIP(hipStreamSynchronize(load_stream_));
@@ -415,6 +470,8 @@ int Scene::service_ring(int ring, uint32_t count) {
 	const WorldDims& d = world.dims;
 	const int* pos = h_positions_[ring];
 	if (upload_pending_) BM_HIP(hipEventSynchronize(ev_upload_)); // the staging buffers of the previous upload are free again
+	uint32_t n_moves = 0;
+	std::unordered_map<int, uint32_t> batch_first_resident, batch_move; // per supercell: bricks resident before this batch / its entry in h_moves_
 	for (uint32_t i = 0; i < count; ++i) {
 		const int px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
 		// the positions come back from device memory: never index host arrays with an entry that cannot be a request
@@ -422,7 +479,8 @@ int Scene::service_ring(int ring, uint32_t count) {
 			set_error("brick request ring holds a position outside the world");
 			return BM_ESTATE;
 		}
-		HostSupercell& c = world.supercells[d.supercell_id(px / kSupercell, py / kSupercell, pz / kSupercell)];
+		const int sci = d.supercell_id(px / kSupercell, py / kSupercell, pz / kSupercell);
+		HostSupercell& c = world.supercells[sci];
 		const uint32_t local = static_cast<uint32_t>((px % kSupercell) + (py % kSupercell) * kSupercell + (pz % kSupercell) * kSupercell * kSupercell);
 		const uint32_t word = c.indices[local];
 		if (!(word & BM_BRICK_LOADED_BIT) || (word & BM_BRICK_INDEX_BITS) >= c.bricks.size()) {
@@ -430,12 +488,30 @@ int Scene::service_ring(int ring, uint32_t count) {
 			return BM_ESTATE;
 		}
 		std::memcpy(h_bricks_ + static_cast<size_t>(i) * kBrickWords, c.bricks[word & BM_BRICK_INDEX_BITS].data, sizeof(Brick));
-		// the reference hands out slots in request order (gpu_index_highest++, Scene.cpp:224); here every brick has a
-		// fixed home slot in the exact-fit arena (block order), so the new index word carries that slot
-		h_indices_[i] = c.device_slot[word & BM_BRICK_INDEX_BITS] | BM_BRICK_LOADED_BIT | (word & BM_BRICK_LOD_BITS);
+		// slots are handed out in request order (gpu_index_highest++, Scene.cpp:224); a full pool doubles first
+		// (Scene.cpp:231-251: 2^ceil(log2(highest + 1))) -- here it moves to a larger region of the arena
+		const uint32_t resident_before_batch = batch_first_resident.emplace(sci, c.resident).first->second;
+		if (c.resident >= c.pool_capacity) {
+			const uint32_t grown = std::max<uint32_t>(kStartingPool, c.pool_capacity * 2u);
+			uint32_t fresh = 0;
+			if (int e = region_alloc(grown, &fresh)) return e;
+			// Only the bricks that were resident BEFORE this batch have to be copied (the batch's own bricks are scattered to
+			// base + slot after the bases are published), and only once: a pool that grows twice in one batch moves from
+			// the region it had when the batch began straight to the last one.
+			auto mv = batch_move.find(sci);
+			if (mv == batch_move.end()) {
+				batch_move.emplace(sci, n_moves);
+				h_moves_[n_moves++] = PoolMove{c.pool_base, fresh, resident_before_batch, static_cast<uint32_t>(sci)};
+			} else {
+				h_moves_[mv->second].dst = fresh;
+			}
+			if (c.pool_capacity > 0) region_free_deferred(c.pool_capacity, c.pool_base);
+			c.pool_base = fresh;
+			c.pool_capacity = grown;
+		}
+		h_indices_[i] = c.resident | BM_BRICK_LOADED_BIT | (word & BM_BRICK_LOD_BITS);
 		c.resident++;
 	}
-	// no pool growth (Scene.cpp:231-251): each supercell owns an exact-fit arena region, so `resident` can never overrun it
 	BM_HIP(hipMemcpyAsync(d_bricks_queue_, h_bricks_, static_cast<size_t>(count) * sizeof(Brick), hipMemcpyHostToDevice, load_stream_));    // :228
 	BM_HIP(hipMemcpyAsync(d_indices_queue_, h_indices_, static_cast<size_t>(count) * sizeof(uint32_t), hipMemcpyHostToDevice, load_stream_)); // :229
 	// The scatter kernel rewrites index words that a frame still in flight may be reading and requesting through
@@ -445,6 +521,13 @@ int Scene::service_ring(int ring, uint32_t count) {
 	DeviceScene ring_view = view_;
 	ring_view.load_queue = d_load_queue_[ring];
 	ring_view.load_queue_count = d_load_count_[ring];
+	if (n_moves > 0) { // grown pools: copy their bricks to the new regions and publish the new bases, ahead of the scatter
+		BM_HIP(hipMemcpyAsync(d_moves_, h_moves_, static_cast<size_t>(n_moves) * sizeof(PoolMove), hipMemcpyHostToDevice, load_stream_));
+		launch_pool_moves(d_moves_, n_moves, d_arena_, d_pool_base_, load_stream_);
+		BM_HIP(hipGetLastError());
+	}
+	for (const auto& f : freed_this_batch_) free_regions_[f.first].push_back(f.second); // reusable by the NEXT batch
+	freed_this_batch_.clear();
 	launch_upload(ring_view, d_bricks_queue_, d_indices_queue_, d_arena_, count, load_stream_); // kernel.cu:412
 	BM_HIP(hipGetLastError());
 	BM_HIP(hipMemsetAsync(d_load_count_[ring], 0, sizeof(uint32_t), load_stream_));             // kernel.cu:413
@@ -517,7 +600,9 @@ int Scene::info(bm_scene_info* out) {
 	out->total_bricks = world.generated ? world.total_bricks() : 0;
 	out->resident_bricks = resident_bricks_;
 	out->index_bytes = on_device_ ? static_cast<uint64_t>(d.supercells) * kCellsPerSupercell * 4 : 0;
-	out->brick_bytes = on_device_ ? total_bricks_ * 64 : 0;
+	out->brick_bytes = on_device_ ? arena_capacity_ * 64 : 0;
+	out->pool_bytes = on_device_ ? pool_bricks_ * 64 : 0;
+	out->cube_field_bytes = on_device_ ? cube_field_bytes_ : 0;
 	return 0;
 }
 
@@ -532,13 +617,13 @@ int Scene::device_indices(int supercell, uint32_t* out4096) {
 
 int Scene::device_brick(int supercell, uint32_t device_slot, uint32_t* out16) {
 	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
-	if (supercell < 0 || supercell >= world.dims.supercells || !out16 || device_slot >= world.supercells[supercell].bricks.size()) {
+	if (supercell < 0 || supercell >= world.dims.supercells || !out16 || device_slot >= world.supercells[supercell].resident) {
 		set_error("bad supercell or slot");
 		return BM_EINVAL;
 	}
 	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipDeviceSynchronize());
-	BM_HIP(hipMemcpy(out16, d_arena_ + (static_cast<size_t>(brick_base_[supercell]) + device_slot) * kBrickWords, sizeof(Brick), hipMemcpyDeviceToHost));
+	BM_HIP(hipMemcpy(out16, d_arena_ + (static_cast<size_t>(world.supercells[supercell].pool_base) + device_slot) * kBrickWords, sizeof(Brick), hipMemcpyDeviceToHost));
 	return 0;
 }
 

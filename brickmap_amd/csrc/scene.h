@@ -81,8 +81,7 @@ private:
 
 	// device memory (DeviceScene view)
 	uint32_t* d_index_grid_ = nullptr;
-	SuperInfo* d_super_info_ = nullptr;
-	BlockInfo* d_block_grid_ = nullptr;
+	uint32_t* d_pool_base_ = nullptr;
 	uint32_t* d_arena_ = nullptr;
 	uint8_t* d_cube_field_ = nullptr;
 	uint64_t cube_field_bytes_ = 0;
@@ -106,7 +105,21 @@ private:
 	int ring_cur_ = 0, ring_snapshot_ = 0;
 	hipEvent_t ev_snapshot_ = nullptr, ev_frame_done_ = nullptr;
 
-	std::vector<uint32_t> brick_base_; // host copy of the prefix sums
+	// ---- brick arena: one device allocation that every supercell's pool lives in (Scene.cpp:152-175,231-251 made one
+	// allocator).  Regions are powers of two of at least kStartingPool bricks, handed out from per-size free lists or
+	// from the top of the arena; the arena itself doubles when it is full (a rare, synchronising reallocation).
+	static constexpr uint32_t kStartingPool = 16; // supergrid_starting_size, variables.h:15
+	uint64_t arena_capacity_ = 0, arena_top_ = 0; // bricks
+	uint64_t pool_bricks_ = 0;                    // bricks of capacity currently handed to pools
+	std::vector<uint32_t> free_regions_[32];      // [log2 size]: arena offsets of free regions
+	std::vector<std::pair<int, uint32_t>> freed_this_batch_; // (log2 size, offset) of regions vacated by the batch being built
+	int arena_reserve(uint64_t bricks, bool exact = false); // make the arena at least this large (contents kept); exact: (re)size an EMPTY arena to fit
+	int region_alloc(uint32_t bricks, uint32_t* offset);
+	void region_free_deferred(uint32_t bricks, uint32_t offset);
+	void arena_reset();
+	PoolMove* h_moves_ = nullptr;                 // pinned staging of one batch's pool moves
+	PoolMove* d_moves_ = nullptr;
+	uint32_t moves_cap_ = 0;
 	uint64_t total_bricks_ = 0, resident_bricks_ = 0;
 	int queue_cap_ = 1024;                       // variables.h:35
 	int lod8_ = 600000, lod2_ = 100000;          // variables.h:24-27

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				if (need_setup) {
 					if (shadow) r.n = mk(0.f, 0.f, 0.f); // connect passes a zeroed normal (kernel.cu:338)
 					pstate = shadow ? P_SHD_DONE : P_EXT_DONE;
-					const int st = ray_setup<DBG, 1>(sc, ro, rd, r, tally);
+					const int st = ray_setup<DBG>(sc, ro, rd, r, tally);
 					state = (st == ST_NEED && shadow) ? ST_CONN : st;
 				}
 			}
@@ -381,14 +381,14 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					r.n = pn;
 					shadow = false;
 					pstate = P_EXT_DONE;
-					state = ray_setup<DBG, 1>(sc, hitp, bdir, r, tally);
+					state = ray_setup<DBG>(sc, hitp, bdir, r, tally);
 				}
 			}
 		} else if (phase == 1) {
 			if (BM_TIMED) { runsB++; lanesB += nB; }
 			// ================= phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask DDA, streaming request)
 			if (state == ST_CAND) {
-				const int st = process_candidate<DBG, 1>(sc, fc.campos, r, info, tally, lds_brick);
+				const int st = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick);
 				state = (st == ST_NEED && shadow) ? ST_CONN : st;
 			}
 		} else {
@@ -459,9 +459,20 @@ __global__ void upload_bricks(const DeviceScene sc, const uint32_t* __restrict__
 	const int sci = (px / 16) + (py / 16) * sc.sg_xy + (pz / 16) * sc.sg_xy2;
 	const uint32_t local = static_cast<uint32_t>((px % 16) + (py % 16) * 16 + (pz % 16) * 256);
 	const uint32_t word = indices_queue[i];
-	const uint32_t slot = sc.super_info[sci].brick_base + (word & kIndexBits);
+	const uint32_t slot = sc.pool_base[sci] + (word & kIndexBits);
 	arena_rw[(static_cast<size_t>(slot) << 4) + w] = bricks_queue[(static_cast<size_t>(i) << 4) + w];
 	if (w == 0) sc.index_grid[(static_cast<size_t>(sci) << 12) + local] = word; // plain store: clears unloaded + requested
+}
+
+// Pool growth (Scene.cpp:231-251): copy the resident bricks of every grown pool to its new region and publish the new
+// base.  One workgroup per pool; runs on the load stream ahead of the scatter of the batch that made the pools grow.
+__global__ void move_pools(const PoolMove* __restrict__ moves, uint32_t* __restrict__ arena, uint32_t* __restrict__ pool_base) {
+	const PoolMove m = moves[blockIdx.x];
+	const uint4* src = reinterpret_cast<const uint4*>(arena + (static_cast<size_t>(m.src) << 4));
+	uint4* dst = reinterpret_cast<uint4*>(arena + (static_cast<size_t>(m.dst) << 4));
+	const uint32_t n = m.src == m.dst ? 0u : m.count * 4u; // 16-byte pieces
+	for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+	if (threadIdx.x == 0) pool_base[m.supercell] = m.dst;
 }
 
 // blit_onto_framebuffer (kernel.cu:348-364) into an offscreen float4 buffer
@@ -527,6 +538,11 @@ void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const ui
 	if (count == 0) return;
 	const int per_block = 256 / 16;
 	hipLaunchKernelGGL(upload_bricks, dim3((count + per_block - 1) / per_block), dim3(256), 0, stream, sc, bricks_queue, indices_queue, arena, count);
+}
+
+void launch_pool_moves(const PoolMove* moves, uint32_t count, uint32_t* arena, uint32_t* pool_base, hipStream_t stream) {
+	if (count == 0) return;
+	hipLaunchKernelGGL(move_pools, dim3(count), dim3(256), 0, stream, moves, arena, pool_base);
 }
 
 void launch_resolve(const float* accum, float* out, long long n, hipStream_t stream) {

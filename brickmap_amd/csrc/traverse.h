@@ -146,14 +146,12 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 
 // ---- brick-grid DDA (voxel.cuh:135-261), split into the three pieces the wave scheduler interleaves
 //
-// The reference reads one 32-bit index word per visited cell (two dependent loads through its pointer
-// table).  ~96 % of those words are zero (air), so the walk consults the 64-bit occupancy mask of the cell's
-// 4x4x4-brick block (DeviceScene::block_grid, a dense bordered array) and touches the index grid only at cells
-// known to be non-empty.  A border record of that array is the reference's per-step exit test (voxel.cuh:256).
-// The per-cell arithmetic (axis choice, tmax accumulation) is the reference's, step for step.
-// Everything in the move is straight-line, select-style code: in a 64-lane wave every branch of a hot loop is
-// taken by some lane on almost every iteration, so a rarely-needed path costs its full instruction count anyway
-// ("Why the bookkeeping mattered").
+// The reference reads one 32-bit index word per visited cell (two dependent loads through its pointer table); ~96 % of
+// those words are zero (air).  The walk here reads one byte of the octant cube field per cell it stops in ("cube-field
+// walk" below) and touches the index grid only at cells known to hold a brick; a border byte of that field is the
+// reference's per-step exit test (voxel.cuh:256).  The tmax values it lands on are the reference's, bit for bit.
+// Everything in a move is straight-line, select-style code: in a 64-lane wave every branch of a hot loop is taken by
+// some lane on almost every iteration, so a rarely-needed path costs its full instruction count anyway.
 struct RayState {
 	f3 o, d;            // origin (brick units once set up) and direction
 	float tx, ty, tz;   // tmax
@@ -163,10 +161,8 @@ struct RayState {
 	float tminn;
 	f3 n;               // normal carried in/out of the traversal (voxel.cuh:135 `normal`)
 	int last_step;      // packed-cell increment of the last move (0 before the first): which axis it was, see move_axis
-	unsigned long long fine; // occupancy mask of the current 4x4x4-brick block   } block-mask walk only (load_block / outer_step,
-	uint32_t block_base;     // arena slot of the current block's first brick     } still used by wavefront.hip)
-	uint32_t field_off;      // cube-field walk: byte offset of the ray's octant plane in DeviceScene::cube_field
-	uint32_t cube;           // cube-field walk: edge of the empty cube ahead of the current cell (its cube_field byte)
+	uint32_t field_off;      // byte offset of the ray's octant plane in DeviceScene::cube_field
+	uint32_t cube;           // edge of the empty cube ahead of the current cell (its cube_field byte)
 	float distance;     // result
 	bool hit;
 };
@@ -184,23 +180,6 @@ __device__ __forceinline__ int cell_x(uint32_t p) { return static_cast<int>(p & 
 __device__ __forceinline__ int cell_y(uint32_t p) { return static_cast<int>((p >> 11) & 0x7FFu) - 16; }
 __device__ __forceinline__ int cell_z(uint32_t p) { return static_cast<int>(p >> 22) - 16; }
 
-// Read the record of the block the ray is in (dense bordered grid, device_types.h).  Block coordinate + 1 (border)
-// = (field >> 2) - 3 because of the 16-cell bias; the three "- 3" are folded into the base pointer sc.block_grid.
-// Returns false when the block is a border block: the ray has left the grid.
-__device__ __forceinline__ bool load_block(const DeviceScene& sc, RayState& r) {
-	const uint32_t bx = (r.p >> 2) & 0x1FFu, by = (r.p >> 13) & 0x1FFu, bz = r.p >> 24;
-	// 24-bit multiply-adds (full rate; a 32-bit v_mul_lo_u32 issues at a quarter of it): all operands are < 2^24
-	const uint32_t idx = __umul24(bz, static_cast<uint32_t>(sc.bg_xy)) + (__umul24(by, static_cast<uint32_t>(sc.bg_x)) + bx);
-	const uint4 rec = *reinterpret_cast<const uint4*>(sc.block_grid + idx);
-	r.fine = static_cast<unsigned long long>(rec.x) | (static_cast<unsigned long long>(rec.y) << 32);
-	r.block_base = rec.z;
-	return rec.w == 0u;
-}
-// Cell index inside its block, (x & 3) | (y & 3) << 2 | (z & 3) << 4.  The three 2-bit groups sit at bits 0, 11 and 22 of
-// the packed cell; one 24-bit multiply by 2^18 + 2^9 + 1 lines them up at bits 18..23 (no two partial products overlap).
-__device__ __forceinline__ uint32_t cell_in_block_shifted(uint32_t p) { return __umul24(p & 0x00C01803u, (1u << 18) | (1u << 9) | 1u); } // index << 18, junk elsewhere
-__device__ __forceinline__ int cell_in_block(uint32_t p) { return static_cast<int>((cell_in_block_shifted(p) >> 18) & 63u); }
-__device__ __forceinline__ bool cell_occupied(const RayState& r) { return (r.fine >> ((cell_in_block_shifted(r.p) >> 18) & 63u)) & 1ull; }
 // axis of the last move from its packed increment: +-1 = x, +-2^11 = y, +-2^22 = z, 0 = no move yet (-1).  (A zero
 // increment can only be selected for a direction with a zero component whose tmax of 1e6 is the smallest of the three:
 // impossible for a unit direction inside the grid.)
@@ -302,9 +281,7 @@ __device__ __forceinline__ int walk_round(const DeviceScene& sc, RayState& r, in
 
 // voxel.cuh:136-189: clip against the world box, move onto it, set up the Amanatides-Woo state.
 // Returns the lane's next state: ST_OUTER / ST_CAND, or ST_NEED with r.hit = false when the ray misses the box.
-// WALK selects the empty-space structure the brick-grid walk uses: 0 = per-block occupancy masks (load_block /
-// outer_step), 1 = the octant cube field (field_lookup / field_step / field_jump below).
-template <bool DBG, int WALK = 0>
+template <bool DBG>
 __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const f3 dir, RayState& r, Tally& tally) {
 	r.hit = false;
 	r.d = dir;
@@ -357,45 +334,14 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 	r.dx = static_cast<float>(sx) * rx; r.dy = static_cast<float>(sy) * ry; r.dz = static_cast<float>(sz) * rz;
 	r.last_step = 0;
 	if (DBG) tally.index_loads++; // one per visited cell = the reference's index loads (algorithmic count)
-	if (WALK == 1) {
-		// octant of the direction: a zero component never moves, either plane is valid for it
-		const uint32_t oct = (dir.x < 0.f ? 1u : 0u) | (dir.y < 0.f ? 2u : 0u) | (dir.z < 0.f ? 4u : 0u);
-		r.field_off = oct * sc.cf_plane;
-		return field_lookup(sc, r); // inside the grid: never a border cell
-	}
-	load_block(sc, r); // inside the grid: never a border block
-	return cell_occupied(r) ? ST_CAND : ST_OUTER;
-}
-
-// voxel.cuh:249-258: one Amanatides-Woo move to the next cell.  Returns the next state.
-// Written select-style (no per-axis branches): the only divergent region is the block / supercell
-// boundary crossing.  `t += mask ? delta : 0` is the reference's `tmax += mask * tdelta` for finite deltas.
-template <bool DBG>
-__device__ __forceinline__ int outer_step(const DeviceScene& sc, RayState& r, Tally& tally) {
-	// work on scalar copies: selects between struct members would otherwise pin the struct in scratch memory
-	const float tx = r.tx, ty = r.ty, tz = r.tz;
-	const bool mx = tx < ty && tx < tz;
-	const bool my = ty <= tx && ty < tz; // mx implies !my
-	const bool mz = !(mx || my);
-	const int step_x = r.sx, step_y = r.stepy, step_z = r.stepz;
-	const int step = mx ? step_x : (my ? step_y : step_z);
-	r.p += static_cast<uint32_t>(step); // pos += mask * step
-	r.last_step = step;                 // identifies the axis of this move (see move_axis)
-	r.tx = tx + (mx ? r.dx : 0.f);
-	r.ty = ty + (my ? r.dy : 0.f);
-	r.tz = tz + (mz ? r.dz : 0.f);
-	// The block record is re-read on EVERY move, not only when the move crossed a block boundary: in a 64-lane wave some
-	// lane crosses one on practically every step, so the conditional version executes the same instructions plus the
-	// test and the branch (measured 2 % slower); consecutive reads of one record are L1 hits.  A border record means
-	// the ray has left the grid (the exit test of voxel.cuh:256).
-	const bool inside = load_block(sc, r); // false: left the grid, a miss (r.hit stays false; a border record's mask is 0)
-	if (DBG && inside) tally.index_loads++;
-	const bool occupied = static_cast<uint32_t>(r.fine >> ((cell_in_block_shifted(r.p) >> 18) & 63u)) & 1u;
-	return inside ? (occupied ? ST_CAND : ST_OUTER) : ST_NEED; // select, not branch: every path of this loop costs full issue
+	// octant of the direction: a zero component never moves, either plane is valid for it
+	const uint32_t oct = (dir.x < 0.f ? 1u : 0u) | (dir.y < 0.f ? 2u : 0u) | (dir.z < 0.f ? 4u : 0u);
+	r.field_off = oct * sc.cf_plane;
+	return field_lookup(sc, r); // inside the grid: never a border cell
 }
 
 // voxel.cuh:200-247: the current cell holds a non-empty brick -- read its index word and resolve it.
-template <bool DBG, int WALK = 0>
+template <bool DBG>
 __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const int* campos, RayState& r, HitInfo& info, Tally& tally,
 													 unsigned long long* lds_brick) {
 	const int px = cell_x(r.p), py = cell_y(r.p), pz = cell_z(r.p);
@@ -403,25 +349,13 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	// inside the grid 0 <= pos < cells, so >>4 and &15 equal the reference's signed /16 and %16
 	const uint32_t sci = static_cast<uint32_t>((px >> 4) + (py >> 4) * sc.sg_xy + (pz >> 4) * sc.sg_xy2);
 	const uint32_t flat = (sci << 12) + static_cast<uint32_t>((px & 15) + ((py & 15) << 4) + ((pz & 15) << 8));
-	// Home slot of this brick: block base + rank of its bit in the block mask.  It does not depend on the index
-	// word, so the 64-byte brick read is issued together with the index-word read instead of behind it (every
-	// non-empty cell owns its slot whether or not the brick is resident, so the read is always in bounds).
-	uint32_t index, pool = 0u;
+	// the reference's addressing (voxel.cuh:222): pool of the supercell + the 12-bit slot carried by the index word.  The
+	// pool base is read together with the index word; the brick is fetched once the word says it is resident and close
+	// enough to be walked at voxel level.
+	const uint32_t pool = sc.pool_base[sci];
+	const uint32_t index = sc.index_grid[flat];
 	BrickRegs brick;
-	if (WALK == 1) {
-		// the reference's addressing (voxel.cuh:222): pool of the supercell + the 12-bit slot carried by the index word.
-		// The pool base is read together with the index word; the brick is fetched once the word says it is resident
-		// and close enough to be walked at voxel level.
-		pool = sc.super_info[sci].brick_base;
-		index = sc.index_grid[flat];
-		brick.q0 = brick.q1 = brick.q2 = brick.q3 = make_uint4(0u, 0u, 0u, 0u);
-	} else {
-		const int ci = cell_in_block(r.p);
-		const uint32_t slot = r.block_base + static_cast<uint32_t>(__popcll(r.fine & ((1ull << ci) - 1ull)));
-		const uint4* bq = reinterpret_cast<const uint4*>(sc.brick_arena + (static_cast<size_t>(slot) << 4));
-		index = sc.index_grid[flat];
-		brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
-	}
+	brick.q0 = brick.q1 = brick.q2 = brick.q3 = make_uint4(0u, 0u, 0u, 0u);
 	// voxel.cuh:202-206, by select: entry normal and entry distance from the axis of the last move; a ray that starts
 	// inside this cell (no move yet) keeps its normal and enters at distance 0
 	const int axis = move_axis(r.last_step);
@@ -450,10 +384,8 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	} else if (index & kLoadedBit) {
 		if (DBG) tally.brick_tests++;
 		int sub = 0;
-		if (WALK == 1) {
-			const uint4* bq = reinterpret_cast<const uint4*>(sc.brick_arena + (static_cast<size_t>(pool + (index & kIndexBits)) << 4));
-			brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
-		}
+		const uint4* bq = reinterpret_cast<const uint4*>(sc.brick_arena + (static_cast<size_t>(pool + (index & kIndexBits)) << 4));
+		brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
 		const f3 o8 = (r.o + r.d * new_distance) * 8.f - r.n * kEpsilon;
 		if (intersect_grid<8, DBG>(o8, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick)) {
 			r.distance = new_distance * 8.f + sub_distance + r.tminn;

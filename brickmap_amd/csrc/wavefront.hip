@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, DBG ? 4 : 6) void wf_trace(const DeviceScene s
 						r.n = mk(c.y, c.z, c.w);
 					}
 					have = true;
-					state = ray_setup<DBG, 1>(sc, o, d, r, tally);
+					state = ray_setup<DBG>(sc, o, d, r, tally);
 				}
 				cur += take;
 			}
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, DBG ? 4 : 6) void wf_trace(const DeviceScene s
 		if (nB >= (live + BM_WF_QUORUM_DIV - 1) / BM_WF_QUORUM_DIV || nA == 0) {
 			// ---- phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask walk, streaming request)
 			if (DBG) { runsB++; lanesB += nB; }
-			if (state == ST_CAND) state = process_candidate<DBG, 1>(sc, fc.campos, r, info, tally, lds_brick);
+			if (state == ST_CAND) state = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick);
 		} else {
 			// ---- phase A: brick-grid walk (trace.hip phase A): a jump pass for every walking lane when enough of them have
 			// an empty cube ahead, single moves otherwise
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScen
 					d = mk(u.w, v.x, v.y);
 					r.n = mk(w2.y, w2.z, w2.w);
 				}
-				state = ray_setup<DBG, 1>(sc, o, d, r, tally);
+				state = ray_setup<DBG>(sc, o, d, r, tally);
 				ended = state == ST_NEED; // missed the world box
 				if (!ended) cold[idx] = make_float4(r.o.x, r.o.y, r.o.z, r.tminn); // read back by candidate resolution
 			}
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : 4) void wf_trace_wg(const DeviceScen
 					r.o = mk(c.x, c.y, c.z);
 					r.tminn = c.w;
 					r.d = mk(q[3], q[4], q[5]);
-					state = process_candidate<DBG, 1>(sc, fc.campos, r, info, tally, lds_brick);
+					state = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick);
 					if (state == ST_NEED) ended = true;
 				}
 			} else if (nAw > 0) {

@@ -117,8 +117,6 @@ void World::build_supercell(int sx, int sy, int sz, const float* heights) {
 	cell.indices.assign(kCellsPerSupercell, 0u);
 	cell.bricks.clear();
 	cell.resident = 0;
-	cell.coarse_mask = 0;
-	for (auto& m : cell.fine_mask) m = 0;
 
 	// per brick column: lowest / highest terrain height under its 8x8 footprint
 	float lo[kSupercell * kSupercell], hi[kSupercell * kSupercell];
@@ -161,28 +159,9 @@ void World::build_supercell(int sx, int sy, int sz, const float* heights) {
 						}
 				}
 				cell.bricks.push_back(brick);
-				const int block = (bx >> 2) + 4 * (by >> 2) + 16 * (bz >> 2);
-				cell.coarse_mask |= 1ull << block;
-				cell.fine_mask[block] |= 1ull << ((bx & 3) + 4 * (by & 3) + 16 * (bz & 3));
 				cell.indices[bx + by * kSupercell + bz * kSupercell * kSupercell] =
 					static_cast<uint32_t>(cell.bricks.size() - 1) | 0x80000000u | (lod << 12); // Scene.cpp:104
 			}
-	}
-	cell.build_device_order();
-}
-
-void HostSupercell::build_device_order() {
-	device_slot.assign(bricks.size(), 0);
-	uint16_t next = 0;
-	for (int block = 0; block < 64; ++block) {
-		block_base[block] = next;
-		const int bx = (block & 3) * 4, by = ((block >> 2) & 3) * 4, bz = (block >> 4) * 4;
-		for (int cell = 0; cell < 64; ++cell) {
-			if (!((fine_mask[block] >> cell) & 1ull)) continue;
-			const int x = bx + (cell & 3), y = by + ((cell >> 2) & 3), z = bz + (cell >> 4);
-			const uint32_t word = indices[x + y * kSupercell + z * kSupercell * kSupercell];
-			device_slot[word & 0xFFFu] = next++;
-		}
 	}
 }
 

@@ -21,15 +21,10 @@ static_assert(sizeof(Brick) == 64, "a brick is one 64-byte record");
 struct HostSupercell {               // Scene::Supercell, Scene.h:21-29 (host part)
 	std::vector<uint32_t> indices;   // 4096 words: slot | loaded | lod<<12, 0 = empty brick
 	std::vector<Brick> bricks;       // non-empty bricks in generation order
-	uint32_t resident = 0;           // gpu_index_highest: next free slot of this supercell's arena region
-	// occupancy summary for the GPU traversal: which 4x4x4-brick blocks / which bricks are non-empty
-	uint64_t coarse_mask = 0;
-	uint64_t fine_mask[64] = {};
-	// device arena order: bricks of a block are contiguous, blocks in index order, bricks in mask-bit order, so that
-	// the arena slot of a brick follows from its block's base and a popcount of the block mask
-	uint16_t block_base[64] = {};        // device slot (within the supercell) of each block's first brick
-	std::vector<uint16_t> device_slot;  // host brick number -> device slot within the supercell
-	void build_device_order();
+	uint32_t resident = 0;           // gpu_index_highest: next free slot of this supercell's pool
+	// device pool of this supercell (Scene::Supercell gpu_count / gpu_index_highest, Scene.h:24-27), kept by Scene
+	uint32_t pool_capacity = 0;      // bricks the pool can hold (0 = no pool yet)
+	uint32_t pool_base = 0;          // first arena slot of the pool
 };
 
 struct WorldDims {

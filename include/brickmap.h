@@ -81,7 +81,9 @@ typedef struct bm_scene_info {
 	int32_t generated, on_device;
 	uint64_t total_bricks;          /* non-empty bricks on the host                      */
 	uint64_t resident_bricks;       /* bricks currently in the device arena              */
-	uint64_t index_bytes, brick_bytes; /* device allocations                             */
+	uint64_t index_bytes, brick_bytes; /* device allocations: index grid; brick arena as allocated (grows by residency) */
+	uint64_t pool_bytes;            /* part of the arena handed to supercell pools (16-brick pools that double, Scene.cpp:231-251) */
+	uint64_t cube_field_bytes;      /* octant cube field of the walk (8 bytes per brick cell) */
 } bm_scene_info;
 
 /* traversal counters (BM_FLAG_COUNTERS); same order as oracle/oracle.c orc_counters */

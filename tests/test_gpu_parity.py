@@ -102,24 +102,19 @@ def test_sky_model_matches(bm, orc, torch_cuda):
 def test_world_on_device_matches_oracle(bm, orc, torch_cuda, scene256, world256):
     info = scene256.info()
     assert info["total_bricks"] == world256.total_bricks() and info["resident_bricks"] == info["total_bricks"]
-    assert info["index_bytes"] == world256.nsc * 16384 and info["brick_bytes"] == 64 * info["total_bricks"]
+    assert info["index_bytes"] == world256.nsc * 16384 and info["pool_bytes"] == 64 * info["total_bricks"] <= info["brick_bytes"]
+    assert info["cube_field_bytes"] == 8 * 34 ** 3
     for sc in range(world256.nsc):
         idx, bricks = scene256.host_supercell(sc)  # host side: the reference's words and brick order
         want_idx, want_bricks = world256.sc_indices(sc), world256.sc_bricks(sc)
         assert np.array_equal(idx, want_idx) and np.array_equal(bricks, want_bricks)
-        # device side: same flags / LoD byte; the 12-bit slot is the brick's home slot in the block-ordered arena
+        # device side, "all bricks pre-loaded": the reference's host words (slot | loaded | lod, Scene.cpp:104) and the
+        # supercell's bricks in host order -- pools are the full host brick vectors
         dev = scene256.device_indices(sc)
-        assert np.array_equal(dev & ~np.uint32(0xFFF), want_idx & ~np.uint32(0xFFF))
+        assert np.array_equal(dev, want_idx)
         nz = np.flatnonzero(dev)
-        assert sorted((dev[nz] & 0xFFF).tolist()) == list(range(len(want_bricks)))  # a permutation of the slots
         for local in nz[:: max(1, len(nz) // 40)]:
             assert np.array_equal(scene256.device_brick(sc, int(dev[local] & 0xFFF)), want_bricks[want_idx[local] & 0xFFF])
-        # block order: slots increase with (block, bit) order
-        lx, ly, lz = nz % 16, (nz // 16) % 16, nz // 256
-        block = (lx >> 2) + 4 * (ly >> 2) + 16 * (lz >> 2)
-        bit = (lx & 3) + 4 * (ly & 3) + 16 * (lz & 3)
-        order = np.lexsort((bit, block))
-        assert np.array_equal(dev[nz][order] & 0xFFF, np.arange(len(nz), dtype=np.uint32))
 
 
 def test_config1_primary_rays_golden(bm, orc, torch_cuda):
@@ -524,7 +519,9 @@ def test_config5_like_lod_world_at_scale(bm, orc, torch_cuda):
     """BASELINE config 5 geometry: 32^3 superchunks (4096^3 voxels, 512 MiB index grid, ~4.3 GiB of bricks), reference
     LoD thresholds (all three levels occur), 8 segments, at a reduced frame; every 64th row compared with the oracle."""
     G, W, H = 4096, 1024, 576
-    scene = bm.Scene(G, G, device=0).generate().preload_all()
+    scene = bm.Scene(G, G, device=0)
+    scene.set_queue_capacity(1 << 20)
+    scene.generate().preload_all()
     info = scene.info()
     assert info["index_bytes"] == 512 * 1024 * 1024 and info["supercells"] == 32768
     cam, ocam = cameras(bm, orc, G)
@@ -542,6 +539,52 @@ def test_config5_like_lod_world_at_scale(bm, orc, torch_cuda):
     rows = bm.dist.shard_rows(H, 1, 5, 64)
     assert np.array_equal(dbg[rows], odbg[rows])
     assert_radiance(acc[rows], oacc[rows])
+    # ---- the same view STREAMED: pools start at 16 bricks and double (Scene.cpp:231-251), the arena grows with
+    # residency -- LoD keeps most of the world's ~4.3 GiB of bricks out of it -- and the steady-state image is the
+    # resident one bit for bit
+    assert info["pool_bytes"] == 64 * info["total_bricks"] <= info["brick_bytes"]
+    scene.reset_residency()
+    plain = bm.FrameParams(W, H, spp=1, max_bounces=7)
+    for _ in range(200):
+        gpu_render(bm, torch_cuda, scene, cam, plain, want_dbg=False)
+        if scene.process_load_queue() == 0:
+            break
+    else:
+        pytest.fail("streaming did not reach a steady state")
+    acc_s, dbg_s = gpu_render(bm, torch_cuda, scene, cam, bm.FrameParams(W, H, spp=1, max_bounces=7))
+    assert np.array_equal(dbg_s, dbg) and np.array_equal(acc_s, acc)
+    streamed = scene.info()
+    assert 0 < streamed["resident_bricks"] < info["total_bricks"] // 8
+    assert 64 * streamed["resident_bricks"] <= streamed["pool_bytes"] <= streamed["brick_bytes"] < 64 * info["total_bricks"] // 4
+    scene.close()
+
+
+def test_pool_growth_keeps_bricks_intact(bm, orc, torch_cuda):
+    """Streaming with a tiny request ring: pools grow 16 -> 32 -> ... one batch at a time (moves between arena regions,
+    freed regions reused); at steady state every loaded word points at exactly its brick."""
+    G = 256
+    scene = bm.Scene(G, G, device=0)
+    scene.set_queue_capacity(48)
+    scene.generate()
+    w = orc.World(G, G)
+    cam, _ = cameras(bm, orc, G)
+    p = bm.FrameParams(200, 150, spp=1, max_bounces=3)
+    for _ in range(2000):
+        gpu_render(bm, torch_cuda, scene, cam, p, want_dbg=False)
+        if scene.process_load_queue() == 0:
+            break
+    else:
+        pytest.fail("streaming did not reach a steady state")
+    info = scene.info()
+    assert info["resident_bricks"] > 500 and info["pool_bytes"] >= 64 * info["resident_bricks"]
+    assert max(int((scene.device_indices(sc) & bm.BRICK_LOADED_BIT != 0).sum()) for sc in range(w.nsc)) > 64  # some pool doubled at least twice
+    for sc in range(w.nsc):
+        dev, host_idx, host_bricks = scene.device_indices(sc), w.sc_indices(sc), w.sc_bricks(sc)
+        loaded = np.flatnonzero(dev & bm.BRICK_LOADED_BIT)
+        slots = dev[loaded] & 0xFFF
+        assert sorted(slots.tolist()) == list(range(len(loaded)))  # request order: dense, each slot once
+        for local in loaded[:: max(1, len(loaded) // 60)]:
+            assert np.array_equal(scene.device_brick(sc, int(dev[local] & 0xFFF)), host_bricks[host_idx[local] & 0xFFF])
     scene.close()
 
 
