@@ -83,6 +83,8 @@ def lib():
             "orc_world_total_uploaded": (C.c_uint64, [vp]),
             "orc_world_hash": (C.c_uint64, [vp]),
             "orc_upload": (C.c_uint32, [vp]),
+            "orc_world_set_overlapped": (None, [vp, i]),
+            "orc_process_load_queue_overlapped": (C.c_uint32, [vp]),
             "orc_process_load_queue": (C.c_uint32, [vp]),
             "orc_intersect_brick": (i, [vp, vp, vp, vp, vp, vp]),
             "orc_intersect_byte": (i, [vp, vp, vp, vp, C.c_uint32, vp]),
@@ -220,6 +222,14 @@ class World:
 
     def upload(self):
         return int(self.L.orc_upload(self.h))
+
+    def set_overlapped(self, on):
+        """Two-ring servicing with the reference's two-frame request -> resident latency (orc_process_load_queue_overlapped);
+        Wavefront.frame() then uses it instead of the reference-order upload / process_load_queue pair."""
+        self.L.orc_world_set_overlapped(self.h, int(on))
+
+    def process_load_queue_overlapped(self):
+        return int(self.L.orc_process_load_queue_overlapped(self.h))
 
     def intersect_voxel(self, origin, direction, campos, normal=(0, 0, 0), distance=1e20):
         o = np.asarray(origin, np.float32)

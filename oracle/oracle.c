@@ -217,6 +217,10 @@ typedef struct {
 	uint32_t* bricks_queue;  /* queue_cap * 16 */
 	uint32_t* indices_queue; /* queue_cap      */
 	uint64_t total_uploaded;
+	/* overlapped servicing (the product's two-ring mode, see orc_process_load_queue_overlapped) */
+	int overlapped;
+	i3* pending;            /* the ring copied out by the previous call, queue_cap entries */
+	uint32_t pending_count;
 } orc_world;
 
 typedef struct {
@@ -247,6 +251,7 @@ ORC_API orc_world* orc_world_create(int grid_size, int grid_height) {
 	w->load_queue = (i3*)calloc((size_t)w->queue_cap, sizeof(i3));
 	w->bricks_queue = (uint32_t*)calloc((size_t)w->queue_cap * 16, 4);
 	w->indices_queue = (uint32_t*)calloc((size_t)w->queue_cap, 4);
+	w->pending = (i3*)calloc((size_t)w->queue_cap, sizeof(i3));
 	return w;
 }
 ORC_API void orc_world_destroy(orc_world* w) {
@@ -254,7 +259,7 @@ ORC_API void orc_world_destroy(orc_world* w) {
 	for (int i = 0; i < w->nsc; i++) {
 		free(w->sc[i].bricks); free(w->sc[i].indices); free(w->sc[i].dev_indices); free(w->sc[i].dev_bricks);
 	}
-	free(w->sc); free(w->load_queue); free(w->bricks_queue); free(w->indices_queue); free(w);
+	free(w->sc); free(w->load_queue); free(w->bricks_queue); free(w->indices_queue); free(w->pending); free(w);
 }
 ORC_API void orc_world_set_lod(orc_world* w, int lod8, int lod2) { w->lod_distance_8x8x8 = lod8; w->lod_distance_2x2x2 = lod2; }
 ORC_API void orc_world_set_queue_cap(orc_world* w, int cap) {
@@ -262,8 +267,11 @@ ORC_API void orc_world_set_queue_cap(orc_world* w, int cap) {
 	w->load_queue = (i3*)realloc(w->load_queue, (size_t)cap * sizeof(i3));
 	w->bricks_queue = (uint32_t*)realloc(w->bricks_queue, (size_t)cap * 64);
 	w->indices_queue = (uint32_t*)realloc(w->indices_queue, (size_t)cap * 4);
+	w->pending = (i3*)realloc(w->pending, (size_t)cap * sizeof(i3));
+	w->pending_count = 0;
 	w->load_queue_count = 0;
 }
+ORC_API void orc_world_set_overlapped(orc_world* w, int overlapped) { w->overlapped = overlapped; }
 
 /* heights of one supercell column (Scene.cpp:47-58).  The reference recomputes this for every
  * z-layer supercell; it is a pure function of (sx, sy), so it is computed once per column here. */
@@ -354,6 +362,7 @@ ORC_API void orc_world_reset_device(orc_world* w, int preload_all) {
 		}
 	}
 	w->load_queue_count = 0;
+	w->pending_count = 0;
 	w->total_uploaded = 0;
 }
 
@@ -445,6 +454,36 @@ ORC_API uint32_t orc_process_load_queue(orc_world* w) {
 		}
 	}
 	return count;
+}
+
+/* Overlapped servicing -- the product's two-ring mode (brickmap_amd/csrc/scene.cpp Scene::process_load_queue): the host
+ * never waits for the frame it has just launched.  One call, made after frame k,
+ *   (1) stages and uploads the ring that the PREVIOUS call copied out (the requests of frame k-1): they are resident
+ *       from frame k+1 on, i.e. two frames after they were raised -- the reference's latency (its upload kernel runs
+ *       at the start of the next launch_kernels, kernel.cu:407-414, one call after Scene::process_load_queue staged
+ *       the bricks, main.cpp:142-144);
+ *   (2) copies out the ring frame k wrote and hands frame k+1 the other, empty ring.
+ * Bricks whose request sits in a copied-out ring keep their requested bit, so a later frame does not ask again.
+ * Returns the number of bricks uploaded by (1). */
+ORC_API uint32_t orc_process_load_queue_overlapped(orc_world* w) {
+	const uint32_t ring_count = w->load_queue_count > (uint32_t)w->queue_cap ? (uint32_t)w->queue_cap : w->load_queue_count;
+	/* keep the ring frame k wrote aside */
+	i3* ring_copy = (i3*)malloc((size_t)(ring_count ? ring_count : 1) * sizeof(i3));
+	memcpy(ring_copy, w->load_queue, (size_t)ring_count * sizeof(i3));
+	/* (1): run the reference's process_load_queue + upload on the pending ring */
+	uint32_t serviced = 0;
+	if (w->pending_count > 0) {
+		memcpy(w->load_queue, w->pending, (size_t)w->pending_count * sizeof(i3));
+		w->load_queue_count = w->pending_count;
+		orc_process_load_queue(w);
+		serviced = orc_upload(w);
+	}
+	/* (2) */
+	memcpy(w->pending, ring_copy, (size_t)ring_count * sizeof(i3));
+	w->pending_count = ring_count;
+	w->load_queue_count = 0;
+	free(ring_copy);
+	return serviced;
 }
 
 /* ---------------------------------------------------------------- traversal (voxel.cuh:13-261) */
@@ -1159,7 +1198,7 @@ ORC_API void orc_wavefront_frame(orc_wavefront* s, orc_world* w, const orc_camer
 	orc_sky_state sky;
 	sky_state_init(&sky, sun_x, sun_y);
 	const unsigned Q = s->queue_size;
-	orc_upload(w); /* :407-414 */
+	if (!w->overlapped) orc_upload(w); /* :407-414 */
 	/* primary_rays :154-223 */
 	unsigned generated = 0;
 	for (unsigned index = 0;; index++) {
@@ -1243,7 +1282,8 @@ ORC_API void orc_wavefront_frame(orc_wavefront* s, orc_world* w, const orc_camer
 	}
 	s->frame++;
 	/* main.cpp:144-146 */
-	orc_process_load_queue(w);
+	if (w->overlapped) orc_process_load_queue_overlapped(w);
+	else orc_process_load_queue(w);
 	RayQueue* tmp = s->work; s->work = s->next; s->next = tmp;
 }
 

@@ -628,6 +628,40 @@ def test_overlapped_streaming_reaches_the_resident_image(bm, orc, torch_cuda):
     scene.close()
 
 
+def test_overlapped_streaming_matches_oracle_frame_by_frame(bm, orc, torch_cuda):
+    """The two-ring mode against the oracle's model of it (orc_process_load_queue_overlapped): a request raised in frame
+    k is resident from frame k+2 on.  Hit records, request / residency flags and upload counts agree frame by frame
+    while the scene streams in (ring large enough that nothing overflows: the request SET is then deterministic)."""
+    G, W, H = 256, 96, 64
+    scene = bm.Scene(G, G, device=0)
+    scene.set_queue_capacity(1 << 16)
+    scene.generate()
+    scene.set_streaming_mode(True)
+    w = orc.World(G, G)
+    w.set_queue_cap(1 << 16)
+    w.reset_device(False)
+    cam, ocam = cameras(bm, orc, G)
+    uploads = []
+    for k in range(7):
+        p = bm.FrameParams(W, H, spp=1, sample_base=k, max_bounces=3)
+        acc, dbg = gpu_render(bm, torch_cuda, scene, cam, p)
+        oacc, odbg, _, _ = w.render(ocam, orc.make_frame(W, H, spp=1, sample_base=k, max_bounces=3))
+        assert np.array_equal(dbg, odbg), f"frame {k}"
+        assert_radiance(acc, oacc)
+        for sc in range(w.nsc):  # same requested / unloaded / loaded flags and LoD bytes (slots follow the request order, which differs)
+            assert np.array_equal(scene.device_indices(sc) & ~np.uint32(0xFFF), w.sc_dev_indices(sc) & ~np.uint32(0xFFF)), f"frame {k} supercell {sc}"
+        n_gpu, n_cpu = scene.process_load_queue(), w.process_load_queue_overlapped()
+        assert n_gpu == n_cpu, f"call {k}"
+        uploads.append(n_gpu)
+    assert uploads[0] == 0 and uploads[1] > 0  # call 1 only copies out frame 1's ring, call 2 uploads it
+    for _ in range(2):  # drain what the last two frames asked for
+        n_gpu, n_cpu = scene.process_load_queue(), w.process_load_queue_overlapped()
+        assert n_gpu == n_cpu
+        uploads.append(n_gpu)
+    assert sum(uploads) == scene.info()["resident_bricks"]
+    scene.close()
+
+
 def test_reference_flythrough_views_on_native_world(bm, orc, torch_cuda):
     """The reference's native world (4096 x 4096 x 512) from two of its fly-through viewpoints (one inside, one far
     outside the world box, performance_measure.h:4-25); every 54th row compared with the oracle."""

@@ -111,6 +111,40 @@ def test_wavefront_streaming_matches_oracle(bm, orc, torch_cuda):
     wf.close(); scene.close()
 
 
+def test_wavefront_overlapped_streaming_matches_oracle(bm, orc, torch_cuda):
+    """The same loop with the two-ring servicing on both sides (orc_process_load_queue_overlapped): requests become
+    resident two calls after they were raised; queues, statistics and uploads agree frame by frame."""
+    torch = torch_cuda
+    G, W, H, Q = 256, 96, 64, 6144
+    scene = bm.Scene(G, G, device=0)
+    scene.set_queue_capacity(1 << 16)
+    scene.generate()
+    scene.set_streaming_mode(True)
+    w = orc.World(G, G)
+    w.set_queue_cap(1 << 16)
+    w.reset_device(False)
+    w.set_overlapped(True)
+    wf, owf = bm.Wavefront(scene, Q), orc.Wavefront(queue_size=Q, max_bounces=3)
+    p = bm.FrameParams(W, H, max_bounces=3, flags=bm.BM_FLAG_COUNTERS)
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    oacc = np.zeros((H, W, 4), np.float32)
+    cam = bm.Camera(position=(G / 2, G / 8, 0.8 * G), horizontal_angle=0.8, vertical_angle=-0.5).update()
+    ocam = orc.make_camera(cam.position, cam.direction)
+    serviced = []
+    for _ in range(10):
+        wf.frame(cam, p, acc)
+        serviced.append(scene.process_load_queue())
+        ost = owf.frame(w, ocam, W, H, oacc)  # includes the oracle's overlapped servicing
+        compare_frame(wf, owf, wf.stats(), ost)
+    assert_radiance(acc.cpu().numpy(), oacc)
+    cnt, ocnt = wf.counters(), owf.counters()
+    assert cnt == ocnt and ocnt["requests"] > 0 and ocnt["brick_tests"] > 0
+    assert serviced[0] == 0 and serviced[1] > 0
+    scene.process_load_queue(); scene.process_load_queue()  # drain what the last two frames asked for
+    assert ocnt["requests"] == scene.info()["resident_bricks"]
+    wf.close(); scene.close()
+
+
 def test_wavefront_frame1_equals_the_reference_run(bm, torch_cuda):
     """The numbers the reference's own kernels produced for frame 1 at 1080p on its default 4096x4096x512 world
     (SURVEY.md 8c probe; tests/golden/survey_probes.json): survivors, shadow rays, start_position."""
