@@ -60,6 +60,18 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_STEPS_PER_ROUND
 #define BM_STEPS_PER_ROUND 4
 #endif
+#ifndef BM_B_STEP
+#define BM_B_STEP 0
+#endif
+#ifndef BM_JUMP_PASSES
+#define BM_JUMP_PASSES 6
+#endif
+#ifndef BM_JUMP_KEEP_NUM
+#define BM_JUMP_KEEP_NUM 1
+#endif
+#ifndef BM_JUMP_KEEP_DIV
+#define BM_JUMP_KEEP_DIV 4
+#endif
 #ifndef BM_POLICY
 #define BM_POLICY 0
 #endif
@@ -388,7 +400,12 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			if (BM_TIMED) { runsB++; lanesB += nB; }
 			// ================= phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask DDA, streaming request)
 			if (state == ST_CAND) {
-				const int st = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick);
+				int st = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick);
+#if BM_B_STEP
+				// a ray that passed through the brick makes its move out of the cell right here: it is the only thing it can do
+				// next, and near a surface the next cell is often a candidate again
+				if (st == ST_OUTER) st = field_step<DBG>(sc, r, tally);
+#endif
 				state = (st == ST_NEED && shadow) ? ST_CONN : st;
 			}
 		} else {
@@ -400,16 +417,25 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			// cell); otherwise the lanes near the surface make a few single moves and the jumpers wait for company.
 			const int nO = nA - nJ;
 			if (nJ * BM_JUMP_RATIO >= nO) {
-				if (BM_TIMED) { runsJ++; lanesJ += nA; }
-				if (state == ST_JUMP || state == ST_OUTER) {
-					int st;
-					if (jump_possible(r.tx, r.ty, r.tz)) {
-						r.cube = r.cube ? r.cube : 1u; // a cell whose brick the ray just passed through: one plain move
-						st = field_jump<DBG>(sc, r, tally);
-					} else {
-						st = field_step<DBG>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
+				int walkers = nA;
+#pragma unroll 1
+				for (int pass = 0; pass < BM_JUMP_PASSES; ++pass) {
+					if (BM_TIMED) { runsJ++; lanesJ += walkers; }
+					if (state == ST_JUMP || state == ST_OUTER) {
+						int st;
+						if (jump_possible(r.tx, r.ty, r.tz)) {
+							r.cube = r.cube ? r.cube : 1u; // a cell whose brick the ray just passed through: one plain move
+							st = field_jump<DBG>(sc, r, tally);
+						} else {
+							st = field_step<DBG>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
+						}
+						state = (st == ST_NEED && shadow) ? ST_CONN : st;
 					}
-					state = (st == ST_NEED && shadow) ? ST_CONN : st;
+					if (BM_JUMP_PASSES > 1) { // another pass right away while most of the walkers are still walking (saves a scheduler round)
+						const int still = __popcll(__ballot(state == ST_JUMP || state == ST_OUTER));
+						if (still * BM_JUMP_KEEP_DIV < walkers * BM_JUMP_KEEP_NUM || still == 0) break;
+						walkers = still;
+					}
 				}
 			} else {
 #pragma unroll 1

@@ -10,6 +10,10 @@
 #include "device_types.h"
 #include "jump.h"
 
+#ifndef BM_CMP3
+#define BM_CMP3 0 // 1: the walks pick their axis with three float compares instead of the reference's four (see intersect_grid)
+#endif
+
 namespace bm {
 
 namespace {
@@ -121,8 +125,14 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 	// at most 3N-2 cells lie on a line through an N^3 block; the bound only guards against NaN input
 	for (int guard = 3 * N + 1; !solid && inside && guard > 0; --guard) {
 		// select-style move (voxel.cuh:122-130); `t += mask ? delta : 0` is `tmax += mask * tdelta` for finite deltas
+#if BM_CMP3
+		const bool xy = tx < ty; // for ordered operands ty <= tx is !(tx < ty): three compares instead of four (a NaN tmax makes no
+		const bool mx = xy && tx < tz; // sense in the reference either: its loop would never move, voxel.cuh:249-258)
+		const bool my = !xy && ty < tz;
+#else
 		const bool mx = tx < ty && tx < tz;
 		const bool my = ty <= tx && ty < tz; // mx implies !my
+#endif
 		const bool mz = !(mx || my);
 		last = mx ? step_x : (my ? step_y : step_z);
 		cell += static_cast<uint32_t>(last);
@@ -216,8 +226,14 @@ __device__ __forceinline__ int field_lookup(const DeviceScene& sc, RayState& r) 
 template <bool DBG>
 __device__ __forceinline__ int field_step(const DeviceScene& sc, RayState& r, Tally& tally) {
 	const float tx = r.tx, ty = r.ty, tz = r.tz;
+#if BM_CMP3
+	const bool xy = tx < ty; // see intersect_grid: three compares instead of four
+	const bool mx = xy && tx < tz;
+	const bool my = !xy && ty < tz;
+#else
 	const bool mx = tx < ty && tx < tz;
 	const bool my = ty <= tx && ty < tz; // mx implies !my
+#endif
 	const bool mz = !(mx || my);
 	const int step_x = r.sx, step_y = r.stepy, step_z = r.stepz; // scalar copies: selects between struct members pin the struct in scratch
 	const int step = mx ? step_x : (my ? step_y : step_z);
@@ -347,7 +363,8 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	const int px = cell_x(r.p), py = cell_y(r.p), pz = cell_z(r.p);
 	const int sx = r.sx, sy = r.stepy >> 11, sz = r.stepz >> 22; // step signs back from the packed increments
 	// inside the grid 0 <= pos < cells, so >>4 and &15 equal the reference's signed /16 and %16
-	const uint32_t sci = static_cast<uint32_t>((px >> 4) + (py >> 4) * sc.sg_xy + (pz >> 4) * sc.sg_xy2);
+	// (24-bit multiplies: all operands are far below 2^24; a 32-bit v_mul_lo_u32 issues at a quarter of the rate)
+	const uint32_t sci = static_cast<uint32_t>((px >> 4) + __mul24(py >> 4, sc.sg_xy) + __mul24(pz >> 4, sc.sg_xy2));
 	const uint32_t flat = (sci << 12) + static_cast<uint32_t>((px & 15) + ((py & 15) << 4) + ((pz & 15) << 8));
 	// the reference's addressing (voxel.cuh:222): pool of the supercell + the 12-bit slot carried by the index word.  The
 	// pool base is read together with the index word; the brick is fetched once the word says it is resident and close
@@ -363,7 +380,7 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	r.n = mk(axis == -1 ? r.n.x : (axis == 0 ? -static_cast<float>(sx) : 0.f), axis == -1 ? r.n.y : (axis == 1 ? -static_cast<float>(sy) : 0.f),
 			 axis == -1 ? r.n.z : (axis == 2 ? -static_cast<float>(sz) : 0.f));
 	const int ddx = campos[0] - px, ddy = campos[1] - py, ddz = campos[2] - pz;
-	const int lod2 = ddx * ddx + ddy * ddy + ddz * ddz;
+	const int lod2 = __mul24(ddx, ddx) + __mul24(ddy, ddy) + __mul24(ddz, ddz); // |dd| < 2^11: exact
 	float sub_distance = 0.f;
 	if (DBG) info.brick_id = px + py * sc.cells + pz * sc.cells * sc.cells;
 	if (lod2 > sc.lod_distance_8x8x8) {

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Profile evidence for one bench workload on the GPU box (run it through gpurun):
+
+    python tools/profile_workload.py <workload> <round-tag> [bench args...]
+
+writes, under gpurun_out/ (copy what is to be judged into profiles/):
+  <tag>_bench_<workload>.json          the bench line of `python bench.py --workload <workload> --steps S --warmup W`
+  <tag>_kernel_stats_<workload>.csv    rocprofv3 --kernel-trace --stats summary of the SAME command
+  <tag>_pmc_summary_<workload>.json    per-launch averages of bm::trace_paths<false> from separate --pmc passes (kernel-trace
+                                       only, one counter group per pass) + the derived figures DESIGN.md quotes
+Counter units / corrections as MI355X_MICROARCH.md prescribes: FETCH_SIZE, WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts a
+128-byte request as 64 bytes, so it is doubled; WRITE_SIZE as reported.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+KERNEL = "trace_paths<false>"
+PMC_SETS = [
+    "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY",
+    "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR",
+    "GRBM_GUI_ACTIVE TCC_HIT TCC_MISS TCC_REQ",
+    "FETCH_SIZE",
+    "WRITE_SIZE",
+    "TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ",
+]
+
+
+def main():
+    workload, tag = sys.argv[1], sys.argv[2]
+    extra = sys.argv[3:]
+    os.makedirs(OUT, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp")
+    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload] + extra
+    steps = ["--steps", "5", "--warmup", "2"] if "--steps" not in extra else []
+    # 1. the bench line
+    r = subprocess.run(bench + steps, capture_output=True, text=True, cwd="/tmp", env=env)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if not line:
+        print(r.stdout[-2000:], r.stderr[-4000:])
+        raise SystemExit("bench failed")
+    bench_json = json.loads(line[-1])
+    json.dump(bench_json, open(os.path.join(OUT, f"{tag}_bench_{workload}.json"), "w"), indent=1)
+    print("bench:", bench_json["value"], bench_json["unit"], bench_json["ms_per_step"], "ms/step, roofline frac", bench_json["roofline"]["frac"])
+    # 2. kernel trace + stats of the same command
+    d = f"/tmp/prof_{tag}_{workload}"
+    shutil.rmtree(d, ignore_errors=True)
+    subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "p", "--"] + bench + steps + ["--no-cpu-baseline"],
+                   capture_output=True, text=True, cwd="/tmp", env=env)
+    stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    kernel_avg_ns = None
+    if stats:
+        shutil.copy(stats[0], os.path.join(OUT, f"{tag}_kernel_stats_{workload}.csv"))
+        for row in csv.DictReader(open(stats[0])):
+            if KERNEL in row.get("Name", ""):
+                kernel_avg_ns = float(row["AverageNs"])
+                print("rocprofv3 stats:", row["Name"][:60], "calls", row["Calls"], "avg ms", kernel_avg_ns / 1e6)
+    # 3. PMC passes (short runs: 2 steps)
+    tot, n = collections.defaultdict(float), collections.defaultdict(int)
+    for i, group in enumerate(PMC_SETS):
+        d = f"/tmp/pmc_{tag}_{workload}_{i}"
+        shutil.rmtree(d, ignore_errors=True)
+        subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + group.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + bench +
+                       ["--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, cwd="/tmp", env=env)
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if KERNEL in row["Kernel_Name"]:
+                    tot[row["Counter_Name"]] += float(row["Counter_Value"])
+                    n[row["Counter_Name"]] += 1
+    s = {"workload": workload, "per": f"launch of bm::{KERNEL} (average over the {max(n.values()) if n else 0} launches of a short bench run, warm-up and streaming fill included)"}
+    for c in sorted(tot):
+        s[c + ("_KiB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")] = tot[c] / n[c]
+    if "FETCH_SIZE_KiB" in s and "WRITE_SIZE_KiB" in s:
+        hbm = (2.0 * s["FETCH_SIZE_KiB"] + s["WRITE_SIZE_KiB"]) * 1024
+        ms = bench_json["roofline"]["kernel_ms_avg"]
+        s["derived"] = {
+            "hbm_bytes_per_launch (2 x FETCH + WRITE)": hbm,
+            "kernel_ms_avg (bench, HIP events)": ms,
+            "kernel_ms_avg (rocprofv3 --stats)": kernel_avg_ns / 1e6 if kernel_avg_ns else None,
+            "hbm_GBps": hbm / (ms * 1e-3) / 1e9,
+            "frac_of_8TBps_by_counters": hbm / (ms * 1e-3) / 8e12,
+            "frac_of_8TBps_algorithmic": bench_json["roofline"]["frac"],
+            "algorithmic_bytes_per_launch": bench_json["roofline"]["algorithmic_bytes_per_launch"],
+            "tcc_hit_rate": s["TCC_HIT"] / s["TCC_REQ"] if s.get("TCC_REQ") else None,
+            "valu_lane_utilisation": s["SQ_THREAD_CYCLES_VALU"] / (64.0 * s["SQ_ACTIVE_INST_VALU"]) if s.get("SQ_ACTIVE_INST_VALU") else None,
+        }
+    json.dump(s, open(os.path.join(OUT, f"{tag}_pmc_summary_{workload}.json"), "w"), indent=1)
+    print(json.dumps(s.get("derived", {}), indent=1))
+
+
+if __name__ == "__main__":
+    main()
