@@ -73,7 +73,10 @@ BM_JHD float jump_fabs(float x) { return jump_float(jump_bits(x) & 0x7FFFFFFFu);
 // A jump is worth attempting when the smallest tmax is a normal number in [2^-10, 2^19): below that the binades are
 // shorter than one step anyway, above it the 1e6 sentinel of a zero direction component (voxel.cuh:185-187) could share
 // a binade with a live axis.  (-0.0f, a possible first tmax, fails the test as well.)
-constexpr uint32_t kJumpMinBits = (127u - 10u) << 23, kJumpMaxBits = (127u + 19u) << 23;
+#ifndef BM_JUMP_TMIN_EXP
+#define BM_JUMP_TMIN_EXP (-10)
+#endif
+constexpr uint32_t kJumpMinBits = static_cast<uint32_t>(127 + BM_JUMP_TMIN_EXP) << 23, kJumpMaxBits = (127u + 19u) << 23;
 BM_JHD bool jump_possible(float tx, float ty, float tz) {
 	float m = tx < ty ? tx : ty;
 	m = m < tz ? m : tz;

@@ -39,6 +39,18 @@ def test_noise_survey_known_answers(orc):
         assert float(v) == float.fromhex(hexval)
 
 
+def test_noise_block_hash_survey_known_answer(orc):
+    """The surveyor's hash of the 128 x 128 noise block at the origin, computed from the reference's own SimplexNoise without
+    FMA contraction (last row): pins 16384 values at once, and that this build does not contract."""
+    xs, ys = np.meshgrid(np.arange(128, dtype=np.float32), np.arange(128, dtype=np.float32))
+    f = orc.fractal2_grid(8, (xs / np.float32(2048)).ravel(), (ys / np.float32(2048)).ravel())
+    h = 0x811C9DC5
+    for w in f.view(np.uint32).tolist():
+        h = ((h ^ w) * 16777619) & 0xFFFFFFFF
+    assert h == int(PROBES["fractal8_block_fnv1a"]["no_fma_contraction"], 16)
+    assert h != int(PROBES["fractal8_block_fnv1a"]["with_fma_contraction"], 16)
+
+
 def test_sky_survey_known_answers(orc):
     sd = orc.sky_probe([0.0, 0.0, 1.0])["sun_direction"]
     np.testing.assert_allclose(sd, PROBES["sun_direction"], atol=2e-6)
@@ -65,6 +77,7 @@ def test_default_world_brick_counts(default_world):
     sxy = p["grid_size"] // 128
     got = [default_world.sc_nbricks(3 + 5 * sxy + z * sxy * sxy) for z in range(4)]
     assert got == p["supercell_3_5_z_bricks"]
+    assert default_world.nsc * 16384 == p["index_bytes"] and default_world.total_bricks() * 64 == p["brick_bytes"]
 
 
 def test_wavefront_frame1_matches_reference_run(orc, default_world):

@@ -49,6 +49,12 @@ KERNEL(k_cvt, "v_cvt_f32_i32 %0, %4\n")
 KERNEL(k_rcp, "v_rcp_f32 %0, %0\n")
 KERNEL(k_bcnt, "v_bcnt_u32_b32 %4, %5, %4\n")
 KERNEL(k_fma_f64, "v_fma_f64 %6, %6, %6, %6\n")
+KERNEL(k_swap, "v_swap_b32 %0, %1\n")
+KERNEL(k_swap2, "v_swap_b32 %0, %1\nv_swap_b32 %2, %3\n")
+KERNEL(k_mov3, "v_mov_b32 %2, %0\nv_mov_b32 %0, %1\nv_mov_b32 %1, %2\n")
+KERNEL(k_cnd2, "v_cndmask_b32 %2, %0, %1, vcc\nv_cndmask_b32 %1, %1, %0, vcc\nv_mov_b32 %0, %2\n")
+KERNEL(k_readlane, "v_readlane_b32 s10, %0, 3\n")
+KERNEL(k_writelane, "v_writelane_b32 %0, s10, 3\n")
 
 template <typename K>
 static void run(const char* name, K kernel, int per_iter, float* out, int cus) {
@@ -82,5 +88,6 @@ int main() {
 	RUN(k_cmp_cnd, 2); RUN(k_bitop3, 1); RUN(k_mov, 1); RUN(k_salu, 1);
 	RUN(k_and, 1); RUN(k_lshr32, 1); RUN(k_lshl_or, 1); RUN(k_lshl_add, 1); RUN(k_mad24, 1); RUN(k_mul_f32, 1); RUN(k_min_f32, 1); RUN(k_min3_f32, 1);
 	RUN(k_cmp_eq_u32, 1); RUN(k_cvt, 1); RUN(k_rcp, 1); RUN(k_bcnt, 1); RUN(k_fma_f64, 1);
+	RUN(k_swap, 1); RUN(k_swap2, 2); RUN(k_mov3, 3); RUN(k_cnd2, 3); RUN(k_readlane, 1); RUN(k_writelane, 1);
 	return 0;
 }
