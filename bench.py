@@ -397,7 +397,7 @@ def pmc_traffic(workload):
     workload and kernel, and the source is named in the line.  Units and correction as MI355X_MICROARCH.md (HBM section)
     prescribes: FETCH_SIZE and WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, i.e.
     reports half of a 16 B/lane stream, so it is doubled; WRITE_SIZE is taken as reported (uncalibrated per the guide)."""
-    name = "pmc_summary.json" if workload == "config2" else f"pmc_summary_{workload}.json"
+    name = f"pmc_summary_{workload}.json"
     path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_" + name)
     try:
         with open(path) as f:

@@ -63,15 +63,6 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_B_STEP
 #define BM_B_STEP 0
 #endif
-#ifndef BM_JUMP_PASSES
-#define BM_JUMP_PASSES 6
-#endif
-#ifndef BM_JUMP_KEEP_NUM
-#define BM_JUMP_KEEP_NUM 1
-#endif
-#ifndef BM_JUMP_KEEP_DIV
-#define BM_JUMP_KEEP_DIV 4
-#endif
 #ifndef BM_POLICY
 #define BM_POLICY 0
 #endif

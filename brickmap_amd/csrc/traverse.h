@@ -273,17 +273,35 @@ __device__ __forceinline__ int field_jump(const DeviceScene& sc, RayState& r, Ta
 #ifndef BM_JUMP_RATIO
 #define BM_JUMP_RATIO 4 // a move round is a jump pass when (lanes with a cube ahead) * ratio >= (lanes near the surface)
 #endif
+#ifndef BM_JUMP_PASSES
+#define BM_JUMP_PASSES 6 // jump passes per round while at least BM_JUMP_KEEP_NUM / BM_JUMP_KEEP_DIV of the walkers keep walking
+#endif
+#ifndef BM_JUMP_KEEP_NUM
+#define BM_JUMP_KEEP_NUM 1
+#endif
+#ifndef BM_JUMP_KEEP_DIV
+#define BM_JUMP_KEEP_DIV 4
+#endif
 template <bool DBG, int STEPS>
 __device__ __forceinline__ int walk_round(const DeviceScene& sc, RayState& r, int state, int n_jump, int n_outer, Tally& tally, uint32_t& runs, uint32_t& lanes) {
 	if (n_jump * BM_JUMP_RATIO >= n_outer) {
-		if (DBG) { runs++; lanes += static_cast<uint32_t>(n_jump + n_outer); }
-		if (state == ST_JUMP || state == ST_OUTER) {
-			if (jump_possible(r.tx, r.ty, r.tz)) {
-				r.cube = r.cube ? r.cube : 1u; // a cell whose brick the ray just passed through: one plain move
-				state = field_jump<DBG>(sc, r, tally);
-			} else {
-				state = field_step<DBG>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
+		int walkers = n_jump + n_outer;
+#pragma unroll 1
+		for (int pass = 0; pass < BM_JUMP_PASSES; ++pass) {
+			if (DBG) { runs++; lanes += static_cast<uint32_t>(walkers); }
+			if (state == ST_JUMP || state == ST_OUTER) {
+				if (jump_possible(r.tx, r.ty, r.tz)) {
+					r.cube = r.cube ? r.cube : 1u; // a cell whose brick the ray just passed through: one plain move
+					state = field_jump<DBG>(sc, r, tally);
+				} else {
+					state = field_step<DBG>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
+				}
 			}
+			// another pass right away while most of the walkers are still walking: keeps the rays of a wave together on their
+			// way to the next candidate and saves a scheduler round
+			const int still = __popcll(__ballot(state == ST_JUMP || state == ST_OUTER));
+			if (still * BM_JUMP_KEEP_DIV < walkers * BM_JUMP_KEEP_NUM || still == 0) break;
+			walkers = still;
 		}
 	} else {
 #pragma unroll 1
