@@ -27,10 +27,11 @@ namespace bm {
 //   GEN -> [extend ray] -> EXT_DONE (shade) -> [shadow ray] -> SHD_DONE (connect) -> BOUNCE -> [extend ray] ...
 // A wave interleaves three kinds of work, each run only when enough lanes want it (or nothing else can
 // run), so that the expensive, rarely-needed code never executes for a handful of lanes:
-//   phase A  one brick-grid DDA move            lanes in ST_OUTER   (cheap, most of the work)
-//   phase B  index word + 8^3 / 2^3 bitmask DDA  lanes in ST_CAND    (expensive, ~2.5 per ray)
-//   phase C  shade / next primary ray + setup    lanes in ST_NEED    (expensive, once per extend ray)
-//   phase D  connect + stored bounce ray setup   lanes in ST_CONN    (cheap, once per shadow ray)
+//   phase A  the brick-grid walk: exact jumps over empty cubes (ST_JUMP) / single moves near the surface (ST_OUTER),
+//            in bursts of up to BM_JUMP_PASSES passes                                   (jump.h, traverse.h)
+//   phase B  index word + 8^3 / 2^3 bitmask DDA   lanes in ST_CAND              (expensive, ~2.5 per ray)
+//   phase C  shade / next primary ray, connect (lanes in ST_CONN: the result of a shadow ray), and ONE ray set-up for
+//            whatever ray each of those lanes traces next                       (expensive, once per ray)
 // Scheduling changes only WHEN a lane's operations happen, never their operands, so results are
 // identical to the reference's per-ray functions run one ray at a time (the oracle).
 enum : int { P_GEN = 0, P_EXT_DONE = 1, P_SHD_DONE = 2, P_BOUNCE = 3 };
@@ -54,29 +55,11 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_QUORUM_SHADE_DIV
 #define BM_QUORUM_SHADE_DIV 4
 #endif
-#ifndef BM_QUORUM_CONN_DIV
-#define BM_QUORUM_CONN_DIV 8
-#endif
 #ifndef BM_STEPS_PER_ROUND
 #define BM_STEPS_PER_ROUND 4
 #endif
 #ifndef BM_B_STEP
 #define BM_B_STEP 0
-#endif
-#ifndef BM_POLICY
-#define BM_POLICY 0
-#endif
-#ifndef BM_COST_A
-#define BM_COST_A 160
-#endif
-#ifndef BM_COST_B
-#define BM_COST_B 580
-#endif
-#ifndef BM_COST_C
-#define BM_COST_C 550
-#endif
-#ifndef BM_COST_D
-#define BM_COST_D 250
 #endif
 #ifndef BM_REFILL_MIN
 #define BM_REFILL_MIN 16
@@ -149,9 +132,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		// ---- refill: hand pixels to idle lanes, 16 (one 4x4 chunk) at a time
 		const unsigned long long idle = __ballot(state == ST_IDLE);
 		const int nI = __popcll(idle);
-#ifdef BM_TIME_REFILL
-		const unsigned long long t_refill = __builtin_amdgcn_s_memtime();
-#endif
 		if (work_left && nI >= BM_REFILL_MIN) {
 			// One global word serves only ~90 returning atomics per microsecond chip-wide, and a refill stalls the whole
 			// wave until its atomic returns; with thousands of waves on one counter that queue is tens of microseconds
@@ -201,15 +181,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				}
 			}
 		}
-#ifdef BM_TIME_REFILL
-		if (work_left && nI >= 16) cycD += __builtin_amdgcn_s_memtime() - t_refill; // experiment: refill time in the connect slot
-#endif
 		const int nJ = __popcll(__ballot(state == ST_JUMP));
 		const int nA = __popcll(__ballot(state == ST_OUTER)) + nJ; // lanes walking the brick grid, cell by cell or cube by cube
 		const int nB = __popcll(__ballot(state == ST_CAND));
-		const int nC = __popcll(__ballot(state == ST_NEED));
-		const int nD = __popcll(__ballot(state == ST_CONN));
-		const int live = nA + nB + nC + nD;
+		const int nC = __popcll(__ballot(state == ST_NEED || state == ST_CONN)); // shade / generate, and connect (same pass)
+		const int live = nA + nB + nC;
 		if (live == 0) {
 			if (!work_left || --rounds_left < 0) break;
 			continue; // everything idle but chunks remain (only pixels outside the image were handed out)
@@ -217,36 +193,51 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		if (--rounds_left < 0) break;
 		// Policy: an expensive phase runs once a quarter of the live lanes wait for it, the cheap connect phase
 		// once an eighth does; otherwise the DDA keeps moving.  With no lane left in the DDA the largest group runs.
-		const int quorum = (live * BM_QUORUM_NUM + BM_QUORUM_DIV - 1) / BM_QUORUM_DIV, quorum_conn = (live + BM_QUORUM_CONN_DIV - 1) / BM_QUORUM_CONN_DIV;
+		const int quorum = (live * BM_QUORUM_NUM + BM_QUORUM_DIV - 1) / BM_QUORUM_DIV;
 		const int quorum_shade = (live * BM_QUORUM_SHADE_NUM + BM_QUORUM_SHADE_DIV - 1) / BM_QUORUM_SHADE_DIV;
 		int phase; // 0 = A (DDA moves), 1 = B (candidates), 2 = C (shade / generate), 3 = D (connect)
-#if BM_POLICY == 1
-		// greedy: run the phase that serves the most lanes per instruction it costs (costs = wave-level VALU instructions of
-		// one pass, rounded); lanes waiting for an expensive phase pile up until that phase is the best deal
-		{
-			const int eA = nA * (BM_COST_B * BM_COST_C / 64), eB = nB * (BM_COST_A * BM_COST_C / 64), eC = nC * (BM_COST_A * BM_COST_B / 64);
-			const int eD = nD * (BM_COST_A * BM_COST_B / 64) * BM_COST_C / BM_COST_D;
-			phase = 0;
-			int best = eA;
-			if (eB > best) { best = eB; phase = 1; }
-			if (eC > best) { best = eC; phase = 2; }
-			if (eD > best) { best = eD; phase = 3; }
-		}
-#else
 		if (nC >= quorum_shade) phase = 2;
 		else if (nB >= quorum) phase = 1;
-		else if (nD >= quorum_conn) phase = 3;
 		else if (nA > 0) phase = 0;
-		else phase = (nC >= nB && nC >= nD) ? 2 : (nB >= nD ? 1 : 3);
-#endif
+		else phase = nC >= nB ? 2 : 1;
 
 		const unsigned long long t_phase = BM_TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
 		if (phase == 2) {
-			if (BM_TIMED) { runsC++; lanesC += nC; }
+			if (BM_TIMED) {
+				const int n_conn = __popcll(__ballot(state == ST_CONN));
+				runsC++; lanesC += nC - n_conn;
+				if (n_conn) { runsD++; lanesD += n_conn; } // "connect" statistics: passes that held shadow-ray results, and how many
+			}
 			// ================= phase C: shade the finished extend ray / generate the next primary ray, then set the new ray up
-			if (state == ST_NEED) {
+			if (state == ST_NEED || state == ST_CONN) {
 				bool need_setup = false;
 				f3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f);
+				if (state == ST_CONN) {
+					// ---- connect (kernel.cu:328-346) -- runs after shade within the same reference frame -- then the stored bounce
+					// ray is set up by the code below, together with the rays of the lanes that were shaded in this pass
+					const bool occluded = r.hit;
+					if (DBG) {
+						tally.shadow_rays++;
+						nsh++;
+						hsh = hmix(hsh, static_cast<uint32_t>(occluded));
+						if (occluded) {
+							hsh = hmix(hsh, static_cast<uint32_t>(info.brick_id));
+							hsh = hmix(hsh, static_cast<uint32_t>(info.sub_id) | (static_cast<uint32_t>(info.level) << 12));
+						}
+					}
+					if (!occluded) {
+						acc.x += scolor.x; acc.y += scolor.y; acc.z += scolor.z;
+					}
+					state = ST_NEED;
+					if (terminated) {
+						s++;
+						pstate = P_GEN; // the next primary ray (or the pixel hand-back) follows below
+					} else {
+						bounces++;
+						pstate = P_BOUNCE; // neither shaded nor generated below: only set up
+						ro = hitp; rd = bdir; r.n = pn; shadow = false; need_setup = true;
+					}
+				}
 				if (pstate == P_EXT_DONE) {
 					// ---- extend finished (kernel.cu:226-238); `hit <=> distance < VERY_FAR`
 					const bool is_hit = r.hit;
@@ -357,36 +348,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					state = (st == ST_NEED && shadow) ? ST_CONN : st;
 				}
 			}
-		} else if (phase == 3) {
-			if (BM_TIMED) { runsD++; lanesD += nD; }
-			// ================= phase D: connect (kernel.cu:328-346) -- runs after shade within the same reference frame --
-			// then the stored bounce ray is set up
-			if (state == ST_CONN) {
-				const bool occluded = r.hit;
-				if (DBG) {
-					tally.shadow_rays++;
-					nsh++;
-					hsh = hmix(hsh, static_cast<uint32_t>(occluded));
-					if (occluded) {
-						hsh = hmix(hsh, static_cast<uint32_t>(info.brick_id));
-						hsh = hmix(hsh, static_cast<uint32_t>(info.sub_id) | (static_cast<uint32_t>(info.level) << 12));
-					}
-				}
-				if (!occluded) {
-					acc.x += scolor.x; acc.y += scolor.y; acc.z += scolor.z;
-				}
-				if (terminated) {
-					s++;
-					pstate = P_GEN;
-					state = ST_NEED; // the next primary ray (or the pixel hand-back) is phase C work
-				} else {
-					bounces++;
-					r.n = pn;
-					shadow = false;
-					pstate = P_EXT_DONE;
-					state = ray_setup<DBG>(sc, hitp, bdir, r, tally);
-				}
-			}
 		} else if (phase == 1) {
 			if (BM_TIMED) { runsB++; lanesB += nB; }
 			// ================= phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask DDA, streaming request)
@@ -441,11 +402,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		}
 		if (BM_TIMED) {
 			const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_phase;
-#ifdef BM_TIME_REFILL
-			if (phase == 0) cycA += dt; else if (phase == 1) cycB += dt; else if (phase == 2) cycC += dt;
-#else
-			if (phase == 0) cycA += dt; else if (phase == 1) cycB += dt; else if (phase == 2) cycC += dt; else cycD += dt;
-#endif
+			if (phase == 0) cycA += dt; else if (phase == 1) cycB += dt; else cycC += dt;
 		}
 	}
 

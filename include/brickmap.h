@@ -97,7 +97,7 @@ typedef struct bm_sched_stats {
 	uint64_t step_runs, step_lanes;           /* phase A: brick-grid DDA moves       */
 	uint64_t candidate_runs, candidate_lanes; /* phase B: index word + bitmask DDA   */
 	uint64_t shade_runs, shade_lanes;         /* phase C: shade / next primary ray   */
-	uint64_t connect_runs, connect_lanes;     /* phase D: connect + bounce ray setup */
+	uint64_t connect_runs, connect_lanes;     /* shade passes that also held finished shadow rays (connect), and how many */
 	/* shader-clock ticks spent in each phase and in the whole scheduler loop, summed over waves */
 	uint64_t step_cycles, candidate_cycles, shade_cycles, connect_cycles, total_cycles;
 	uint64_t jump_runs, jump_lanes;           /* phase A, cube jumps (step_* count the single moves) */

@@ -459,6 +459,7 @@ def test_scheduler_statistics(bm, orc, torch_cuda, scene256):
     assert s["step_lanes"] + 762 * s["jump_lanes"] + c["extend_rays"] + c["shadow_rays"] >= c["index_loads"]
     assert s["step_lanes"] + s["jump_lanes"] + c["extend_rays"] + c["shadow_rays"] < c["index_loads"]  # jumps do skip cells
     assert s["candidate_lanes"] >= c["brick_tests"] and s["shade_lanes"] >= c["extend_rays"] and s["connect_lanes"] == c["shadow_rays"]
+    assert s["connect_runs"] <= s["shade_runs"]  # connect is part of the shade pass
     assert 0 <= s["step_lanes"] <= 64 * s["step_runs"] and 0 < s["jump_lanes"] <= 64 * s["jump_runs"] and s["waves"] > 0
 
 
