@@ -85,13 +85,14 @@ BM_JHD bool jump_possible(float tx, float ty, float tz) {
 
 // #{ j >= 0 : M + j*Q < thr }  for bit patterns of one binade (thr - M <= 2^23), Q >= 1; 0 when thr <= M.
 // The quotient is at most 255 for every axis that can step inside the jump (see dda_jump), so the fp32 estimate is
-// within 1 of the true floor and one exact integer correction in each direction settles it.
+// within 2^-13 of the true quotient and one exact integer correction settles it.
 BM_JHD uint32_t jump_count_below(uint32_t thr, uint32_t M, uint32_t Q, float rcpQ) {
 	const uint32_t a = thr - M - 1u; // garbage when thr <= M: masked at the end
-	uint32_t q = static_cast<uint32_t>(static_cast<float>(a) * rcpQ);
+	// the estimate is biased upwards by 2^-12 (the quotient is below 2^8, its error below 2^-13): it is the true floor or
+	// one more, never less, so a single correction settles it
+	uint32_t q = static_cast<uint32_t>(static_cast<float>(a) * rcpQ + 0.000244140625f);
 	const int32_t rem = static_cast<int32_t>(a - jump_mul24(q, Q)); // q <= 2^9 here, Q <= 2^23
 	q -= rem < 0 ? 1u : 0u;
-	q += rem >= static_cast<int32_t>(Q) ? 1u : 0u;
 	return thr > M ? q + 1u : 0u;
 }
 

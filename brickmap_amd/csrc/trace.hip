@@ -375,12 +375,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					if (BM_TIMED) { runsJ++; lanesJ += walkers; }
 					if (state == ST_JUMP || state == ST_OUTER) {
 						int st;
-						if (jump_possible(r.tx, r.ty, r.tz)) {
-							r.cube = r.cube ? r.cube : 1u; // a cell whose brick the ray just passed through: one plain move
-							st = field_jump<DBG>(sc, r, tally);
-						} else {
-							st = field_step<DBG>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
-						}
+						if (!(r.cube & kCubeNoJump)) st = field_jump<DBG>(sc, r, tally);
+						else st = field_step<DBG>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
 						state = (st == ST_NEED && shadow) ? ST_CONN : st;
 					}
 					if (BM_JUMP_PASSES > 1) { // another pass right away while most of the walkers are still walking (saves a scheduler round)

@@ -207,15 +207,17 @@ __device__ __forceinline__ int move_axis(int last_step) {
 #ifndef BM_JUMP_MIN
 #define BM_JUMP_MIN 4 // smallest cube edge worth a jump (a jump costs about four single steps)
 #endif
+constexpr uint32_t kCubeNoJump = 0x100u; // RayState::cube flag: tmax is outside the range of jump.h, take single moves
 __device__ __forceinline__ int field_lookup(const DeviceScene& sc, RayState& r) {
 	const uint32_t fx = r.p & 0x7FFu, fy = (r.p >> 11) & 0x7FFu, fz = r.p >> 22;
 	// bordered cell coordinate = field - 15 (16-cell bias, one border cell): the three "- 15" are folded into sc.cube_field
 	const uint32_t idx = __umul24(fz, static_cast<uint32_t>(sc.cf_xy)) + (__umul24(fy, static_cast<uint32_t>(sc.cf_x)) + fx) + r.field_off;
 	const uint32_t v = sc.cube_field[idx];
-	r.cube = v;
 	const float m = fminf(fminf(r.tx, r.ty), r.tz);
 	// select-style, no short-circuit: a branchy version costs its full instruction count in a divergent wave anyway
-	const int jump = static_cast<int>(v >= static_cast<uint32_t>(BM_JUMP_MIN)) & static_cast<int>(__float_as_uint(m) - kJumpMinBits < kJumpMaxBits - kJumpMinBits);
+	const bool possible = __float_as_uint(m) - kJumpMinBits < kJumpMaxBits - kJumpMinBits; // jump_possible(): tmax in the range jump.h handles
+	r.cube = possible ? v : (v | kCubeNoJump); // remembered for the walk pass, which may be several scheduler rounds away
+	const int jump = static_cast<int>(v >= static_cast<uint32_t>(BM_JUMP_MIN)) & static_cast<int>(possible);
 	int st = jump ? ST_JUMP : ST_OUTER;
 	st = v == 0u ? ST_CAND : st;
 	st = v == 255u ? ST_NEED : st; // left the grid (voxel.cuh:256): a miss
@@ -255,7 +257,8 @@ __device__ __forceinline__ int field_jump(const DeviceScene& sc, RayState& r, Ta
 	float tx = r.tx, ty = r.ty, tz = r.tz;
 	const float dx = r.dx, dy = r.dy, dz = r.dz;
 	const int step_x = r.sx, step_y = r.stepy, step_z = r.stepz; // scalar copies, see field_step
-	dda_jump(tx, ty, tz, dx, dy, dz, r.cube, cx, cy, cz, axis);
+	const uint32_t n = r.cube & 0xFFu; // (a cell whose brick the ray just passed through has 0: one plain move, valid anywhere)
+	dda_jump(tx, ty, tz, dx, dy, dz, n ? n : 1u, cx, cy, cz, axis);
 	r.tx = tx; r.ty = ty; r.tz = tz;
 	// all three products fit 24-bit signed multiplies: counts <= 255, increments +-1 / +-2^11 / +-2^22
 	r.p += static_cast<uint32_t>(__mul24(static_cast<int>(cx), step_x) + __mul24(static_cast<int>(cy), step_y) + __mul24(static_cast<int>(cz), step_z));
@@ -290,12 +293,8 @@ __device__ __forceinline__ int walk_round(const DeviceScene& sc, RayState& r, in
 		for (int pass = 0; pass < BM_JUMP_PASSES; ++pass) {
 			if (DBG) { runs++; lanes += static_cast<uint32_t>(walkers); }
 			if (state == ST_JUMP || state == ST_OUTER) {
-				if (jump_possible(r.tx, r.ty, r.tz)) {
-					r.cube = r.cube ? r.cube : 1u; // a cell whose brick the ray just passed through: one plain move
-					state = field_jump<DBG>(sc, r, tally);
-				} else {
-					state = field_step<DBG>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
-				}
+				if (!(r.cube & kCubeNoJump)) state = field_jump<DBG>(sc, r, tally);
+				else state = field_step<DBG>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
 			}
 			// another pass right away while most of the walkers are still walking: keeps the rays of a wave together on their
 			// way to the next candidate and saves a scheduler round
