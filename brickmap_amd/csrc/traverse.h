@@ -224,7 +224,8 @@ __device__ __forceinline__ int field_lookup(const DeviceScene& sc, RayState& r) 
 	return st;
 }
 
-// voxel.cuh:249-258: one Amanatides-Woo move to the next cell (select-style, see outer_step), then the new cell's byte.
+// voxel.cuh:249-258: one Amanatides-Woo move to the next cell, then the new cell's byte.  Select-style (no per-axis branches);
+// `t += mask ? delta : 0` is the reference's `tmax += mask * tdelta` for finite deltas.
 template <bool DBG>
 __device__ __forceinline__ int field_step(const DeviceScene& sc, RayState& r, Tally& tally) {
 	const float tx = r.tx, ty = r.ty, tz = r.tz;
