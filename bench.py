@@ -359,14 +359,34 @@ def host_cpu():
     return model, (len(cores) or logical), logical
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the cgroup CPU quota (cpu.max / cfs_quota) if there is one, else the affinity mask."""
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            allowed = min(allowed, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                allowed = min(allowed, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return allowed
+
+
 def cpu_baseline(W, H, max_bounces, G, cam):
     """The oracle's scalar C port of the same per-pixel path (oracle/oracle.c orc_render), timed on the host: one thread
-    per PHYSICAL core (tile-granular dynamic scheduling), plus a 1-thread figure.
+    per USABLE core (physical cores, capped by the cgroup CPU quota; tile-granular dynamic scheduling), plus a 1-thread
+    figure.
     Sample: whole frames of the same workload -- one calibration frame, then enough samples per pixel for roughly 3 s of
     wall time on all cores; 1 thread: every 8th 8-row band of one frame (an eighth of the pixels, spread over the image)."""
     import oracle
     model, physical, logical = host_cpu()
-    threads = max(1, min(physical, 256))
+    quota = cpu_quota()  # the GPU boxes run in a cgroup with a CPU quota far below the core count: more threads only get throttled
+    threads = max(1, min(physical, quota, 256))
     world = oracle.World(G, G, threads=logical)
     world.reset_device(True)
     ocam = oracle.make_camera(cam.position, cam.direction)
@@ -384,8 +404,9 @@ def cpu_baseline(W, H, max_bounces, G, cam):
         "cores": threads,
         "kind": "port",
         "sample": f"{n} samples/pixel of the same {W}x{H} frame ({nominal} nominal rays, "
-                  f"{cnt['extend_rays'] + cnt['shadow_rays']} actual) in {secs:.2f} s on {threads} threads (one per physical core)",
-        "cpu_model": model, "physical_cores": physical, "logical_cpus": logical,
+                  f"{cnt['extend_rays'] + cnt['shadow_rays']} actual) in {secs:.2f} s on {threads} threads "
+                  f"(one per usable core: {physical} physical cores, cgroup CPU quota {quota})",
+        "cpu_model": model, "physical_cores": physical, "logical_cpus": logical, "cpu_quota": quota,
         "one_thread": {"value": round(nominal1 / secs1 / 1e6, 4), "unit": "Mrays/s",
                        "sample": f"every 8th 8-row band of one frame ({nominal1} nominal rays, {cnt1['extend_rays'] + cnt1['shadow_rays']} actual) in {secs1:.2f} s"},
     }

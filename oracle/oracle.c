@@ -984,7 +984,8 @@ typedef struct {
 	orc_counters cnt;
 	volatile int* next_row;
 	int atomic_requests;
-} render_job;
+	char pad[128]; /* one job per thread in an array: keep the per-thread counters of neighbours off each other's cache lines */
+} __attribute__((aligned(128))) render_job;
 
 static int row_in_shard(const orc_frame* f, int y) {
 	int band = f->band_rows > 0 ? f->band_rows : f->height;
@@ -1119,7 +1120,8 @@ ORC_API double orc_render(orc_world* w, const orc_camera* cam, const orc_frame* 
 	if (threads < 1) threads = 1;
 	if (threads > 256) threads = 256;
 	volatile int next_row = 0;
-	render_job* jobs = (render_job*)calloc((size_t)threads, sizeof(render_job));
+	render_job* jobs = (render_job*)aligned_alloc(128, (size_t)threads * sizeof(render_job));
+	memset(jobs, 0, (size_t)threads * sizeof(render_job));
 	pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
 	struct timespec t0, t1;
 	clock_gettime(CLOCK_MONOTONIC, &t0);
