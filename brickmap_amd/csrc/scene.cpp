@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <unordered_map>
@@ -185,6 +186,10 @@ int Scene::init(int grid_size, int grid_height) {
 	compute_units_ = prop.multiProcessorCount; // main.cpp:97 sm_cores
 	blocks_per_cu_[0] = trace_blocks_per_cu(false);
 	blocks_per_cu_[1] = trace_blocks_per_cu(true);
+	if (const char* cap = std::getenv("BM_TRACE_BLOCKS_PER_CU")) { // experiment knob: fewer resident waves per SIMD (1 block = 1 wave per SIMD)
+		const int n = std::atoi(cap);
+		if (n > 0 && n < blocks_per_cu_[0]) blocks_per_cu_[0] = n;
+	}
 
 	return alloc_queue();
 }
