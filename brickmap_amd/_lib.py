@@ -59,7 +59,7 @@ class bm_counters(C.Structure):
 
 
 SCHED_NAMES = ("step_runs", "step_lanes", "candidate_runs", "candidate_lanes", "shade_runs", "shade_lanes", "connect_runs", "connect_lanes",
-               "step_cycles", "candidate_cycles", "shade_cycles", "connect_cycles", "total_cycles", "jump_runs", "jump_lanes", "waves")
+               "step_cycles", "candidate_cycles", "shade_cycles", "drain_cycles", "total_cycles", "jump_runs", "jump_lanes", "waves")
 
 
 class bm_sched_stats(C.Structure):

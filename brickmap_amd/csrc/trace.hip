@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 
 	unsigned long long cycA = 0, cycB = 0, cycC = 0, cycD = 0;
 	const unsigned long long t_begin = BM_TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
+	unsigned long long t_dry = 0ull; // when this wave found the ticket counters empty (BM_TIMED): the rest of its life is the drain
 
 	for (;;) {
 		// ---- refill: hand pixels to idle lanes, 16 (one 4x4 chunk) at a time
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			const uint32_t counter_now = static_cast<uint32_t>(my_counter);
 			if (base + want >= my_tickets) { // this counter is used up: move to the next one (helping out), or finish
 				my_counter = (my_counter + 1) % static_cast<int>(kCounters);
-				if (++counters_done >= static_cast<int>(kCounters)) work_left = false;
+				if (++counters_done >= static_cast<int>(kCounters)) { work_left = false; if (BM_TIMED) t_dry = __builtin_amdgcn_s_memtime(); }
 			}
 			const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
 			if (state == ST_IDLE && rank < want * 16) {
@@ -414,7 +415,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	if (BM_TIMED && counters && lane == 0) {
 		const unsigned long long st[8] = {runsA, lanesA, runsB, lanesB, runsC, lanesC, runsD, lanesD};
 		for (int k = 0; k < 8; ++k) atomicAdd(&counters->sched[k], st[k]);
-		const unsigned long long cy[8] = {cycA, cycB, cycC, cycD, __builtin_amdgcn_s_memtime() - t_begin, runsJ, lanesJ, 1ull};
+		const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+		cycD = t_dry ? t_end - t_dry : 0ull; // "connect" slot: time from the wave's last (failed) refill to its exit = the drain
+		const unsigned long long cy[8] = {cycA, cycB, cycC, cycD, t_end - t_begin, runsJ, lanesJ, 1ull};
 		for (int k = 0; k < 8; ++k) atomicAdd(&counters->cycles[k], cy[k]);
 	}
 }

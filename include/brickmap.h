@@ -99,7 +99,9 @@ typedef struct bm_sched_stats {
 	uint64_t shade_runs, shade_lanes;         /* phase C: shade / next primary ray   */
 	uint64_t connect_runs, connect_lanes;     /* shade passes that also held finished shadow rays (connect), and how many */
 	/* shader-clock ticks spent in each phase and in the whole scheduler loop, summed over waves */
-	uint64_t step_cycles, candidate_cycles, shade_cycles, connect_cycles, total_cycles;
+	uint64_t step_cycles, candidate_cycles, shade_cycles;
+	uint64_t drain_cycles;                    /* from a wave's last (failed) refill to its exit: the end-of-frame drain */
+	uint64_t total_cycles;
 	uint64_t jump_runs, jump_lanes;           /* phase A, cube jumps (step_* count the single moves) */
 	uint64_t waves;
 } bm_sched_stats;

@@ -16,9 +16,11 @@ scene.counters_reset()
 scene.render(cam, bm.FrameParams(W, H, spp=spp, max_bounces=3, flags=bm.BM_FLAG_COUNTERS), acc)
 c = scene.counters(); s = scene.sched_stats()
 print(c)
-for k in ("step", "candidate", "shade", "connect"):
+for k in ("step", "candidate", "shade"):
     r, l = s[k+"_runs"], s[k+"_lanes"]
     cy = s[k+"_cycles"]
     print("%-10s runs %10d  avg active lanes %5.1f   cycles/run %8.1f   share of wave time %5.1f%%" % (k, r, l/max(r,1), cy/max(r,1), 100.0*cy/s["total_cycles"]))
+print("connect    in %d shade passes, %5.1f lanes each" % (s["connect_runs"], s["connect_lanes"]/max(s["connect_runs"],1)))
 print("jump       runs %10d  avg active lanes %5.1f" % (s["jump_runs"], s["jump_lanes"]/max(s["jump_runs"],1)))
+print("drain      %5.1f%% of a wave's lifetime lies after its last refill attempt" % (100.0*s["drain_cycles"]/s["total_cycles"]))
 print("waves", s["waves"], "avg wave cycles", s["total_cycles"]/s["waves"])

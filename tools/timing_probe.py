@@ -14,10 +14,11 @@ scene.render(cam, bm.FrameParams(W, H, spp=1, sample_base=9, **kw), acc)
 torch.cuda.synchronize()
 print("kernel ms", scene.last_render_ms())
 s = scene.sched_stats()
-for k in ("step", "candidate", "shade", "connect"):
+for k in ("step", "candidate", "shade"):
     r, l, cy = s[k+"_runs"], s[k+"_lanes"], s[k+"_cycles"]
     print("%-10s runs %10d  avg lanes %5.1f  cycles/run %8.1f  share %5.1f%%" % (k, r, l/max(r,1), cy/max(r,1), 100.0*cy/s["total_cycles"]))
 print("jump       runs %10d  avg lanes %5.1f   (time inside 'step')" % (s["jump_runs"], s["jump_lanes"]/max(s["jump_runs"],1)))
-other = s["total_cycles"] - sum(s[k+"_cycles"] for k in ("step", "candidate", "shade", "connect"))
+print("drain (from a wave's last refill attempt to its exit): %5.1f%% of its lifetime on average" % (100.0 * s["drain_cycles"] / s["total_cycles"]))
+other = s["total_cycles"] - s["drain_cycles"] - sum(s[k+"_cycles"] for k in ("step", "candidate", "shade"))
 print("scheduler + refill share %5.1f%%" % (100.0*other/s["total_cycles"]))
 print("waves", s["waves"], "avg wave cycles", s["total_cycles"]/max(s["waves"],1))
