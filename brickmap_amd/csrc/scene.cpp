@@ -562,7 +562,7 @@ int Scene::process_load_queue(uint32_t* serviced) {
 	}
 	// ---- overlapped mode: never wait for the GPU.  (1) service the ring that was copied out by the previous call,
 	// (2) start copying out the ring the last frame wrote, behind that frame, on the load stream, (3) hand the other
-	// ring to the next frame.  Request -> resident takes two frames, as in the reference.
+	// ring to the next frame.  A brick requested in frame k is resident from frame k+2 on (reference order: from k+1 on).
 	if (snapshot_pending_) {
 		BM_HIP(hipEventSynchronize(ev_snapshot_));
 		snapshot_pending_ = false;

@@ -121,7 +121,7 @@ BM_API int bm_scene_set_queue_capacity(bm_scene* scene, int capacity);
 /* 0 (default): bm_scene_process_load_queue waits for the frame and services its requests at once (reference order,
  * main.cpp:142-144).  1: overlapped -- two request rings alternate; the call services the ring copied out by the
  * previous call and starts the asynchronous copy-out of the last frame's ring on the load stream, so the host never
- * waits for the GPU (request -> resident = 2 frames, as in the reference). */
+ * waits for the GPU (a brick requested in frame k is resident from frame k+2 on; reference order: from frame k+1 on). */
 BM_API int bm_scene_set_streaming_mode(bm_scene* scene, int overlapped);
 /* Scene::generate (Scene.cpp:118-194): CPU world build on `threads` host threads, then the
  * device allocations in the reference's initial state (nothing resident: unloaded|lod). */

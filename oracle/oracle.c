@@ -459,9 +459,8 @@ ORC_API uint32_t orc_process_load_queue(orc_world* w) {
 /* Overlapped servicing -- the product's two-ring mode (brickmap_amd/csrc/scene.cpp Scene::process_load_queue): the host
  * never waits for the frame it has just launched.  One call, made after frame k,
  *   (1) stages and uploads the ring that the PREVIOUS call copied out (the requests of frame k-1): they are resident
- *       from frame k+1 on, i.e. two frames after they were raised -- the reference's latency (its upload kernel runs
- *       at the start of the next launch_kernels, kernel.cu:407-414, one call after Scene::process_load_queue staged
- *       the bricks, main.cpp:142-144);
+ *       from frame k+1 on -- one frame later than in the reference's order, where process_load_queue after frame k-1
+ *       stages them and the upload kernel at the start of frame k scatters them (kernel.cu:407-414, main.cpp:142-144);
  *   (2) copies out the ring frame k wrote and hands frame k+1 the other, empty ring.
  * Bricks whose request sits in a copied-out ring keep their requested bit, so a later frame does not ask again.
  * Returns the number of bricks uploaded by (1). */
