@@ -111,3 +111,19 @@ def test_cpp_mirror_header_compiles_standalone(tmp_path):
     probe = tmp_path / "probe.c"
     probe.write_text('#include "brickmap.h"\nint main(void) { bm_frame_params p; (void)p; return sizeof(bm_camera) ? 0 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(probe)])
+
+
+def test_bench_helpers_run_without_a_gpu():
+    """bench.py's host-side helpers: workload table, CPU discovery, and the committed PMC summaries roofline.traffic cites."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.workload("config2") == (1920, 1080, 1, 3, 8, False)  # BASELINE.json configs[1]
+    assert b.workload("config3")[5] and not b.workload("config5")[5]
+    model, physical, logical = b.host_cpu()
+    assert 1 <= physical <= logical and 1 <= b.cpu_quota() <= logical and isinstance(model, str)
+    for wl in ("config2", "config3", "config5"):
+        t = b.pmc_traffic(wl)
+        assert t["traffic"] and t["traffic"] > 0 and f"{b.PROFILE_ROUND}_pmc_summary_{wl}.json" in t["traffic_source"]
+    assert b.pmc_traffic("no-such-workload") == {"traffic": None, "traffic_source": None}
