@@ -703,3 +703,27 @@ def test_sample_items_mode_matches_pixel_items(bm, orc, torch_cuda, scene256):
     # hit records are per pixel: refused in this mode
     with pytest.raises(bm.BrickmapError):
         gpu_render(bm, torch_cuda, scene256, cam, bm.FrameParams(32, 32, spp=2, flags=bm.BM_FLAG_SAMPLE_ITEMS), want_dbg=True, also_plain=False)
+
+
+def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
+    """`bench.py --gpus 2` end to end -- row-band shards with (chunk, sample) work items, pipelined gather to rank 0,
+    max-over-ranks timing, one JSON line -- with both ranks on this GPU and gloo instead of RCCL (BM_BENCH_SHARE_GPU=1).
+    The 8-GPU run itself is the driver's; this pins the code path it takes."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["--decomposition", "samples"]):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "config1"] + extra
+        env = dict(os.environ, BM_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(line) == 1, r.stdout[-1500:]
+        out = json.loads(line[0])
+        assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
+        assert out["config"]["spp_per_step"] == 8 and "roofline" in out and "cpu_baseline" not in out
+        port += 1
