@@ -178,7 +178,7 @@ int Scene::init(int grid_size, int grid_height) {
 	}
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_counters_), sizeof(DeviceCounters)));
 	BM_HIP(hipMemset(d_counters_, 0, sizeof(DeviceCounters)));
-	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_work_counter_), kWorkCounterBytes));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_work_counter_), kWorkCounterBytes * kTimingRing)); // one block of counters per launch in flight
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_frame_constants_), kTimingRing * sizeof(FrameConstants)));
 	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_frame_constants_), kTimingRing * sizeof(FrameConstants), hipHostMallocDefault));
 	hipDeviceProp_t prop;
@@ -648,7 +648,8 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 	if (dbg && (fp->flags & BM_FLAG_SAMPLE_ITEMS)) { set_error("hit records are per pixel: not available with BM_FLAG_SAMPLE_ITEMS"); return BM_EINVAL; }
 	const bool instrumented = dbg != nullptr || (fp->flags & BM_FLAG_COUNTERS);
 	const int slot = static_cast<int>(launches_ % kTimingRing);
-	BM_HIP(hipMemsetAsync(d_work_counter_, 0, kWorkCounterBytes, stream)); // chunk counters of the persistent kernel
+	uint32_t* const work_counter = d_work_counter_ + static_cast<size_t>(slot) * (kWorkCounterBytes / sizeof(uint32_t)); // this launch's own block
+	BM_HIP(hipMemsetAsync(work_counter, 0, kWorkCounterBytes, stream)); // chunk counters of the persistent kernel
 	// the pinned slot (and its event pair) is reused every kTimingRing launches: make sure the launch that used it last has
 	// consumed it -- a caller that queues hundreds of frames without a sync would otherwise overwrite constants whose copy
 	// has not run yet (the event is almost always complete already, so this costs nothing)
@@ -661,7 +662,7 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 #else
 	DeviceCounters* const counters_arg = (fp->flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr;
 #endif
-	launch_trace(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, d_work_counter_, instrumented,
+	launch_trace(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, work_counter, instrumented,
 				 compute_units_ * blocks_per_cu_[instrumented ? 1 : 0], stream);
 	BM_HIP(hipGetLastError());
 	BM_HIP(hipEventRecord(ev_stop_[slot], stream));

@@ -94,7 +94,7 @@ private:
 	DeviceCounters* d_counters_ = nullptr;
 	FrameConstants* d_frame_constants_ = nullptr; // kTimingRing device copies, one per in-flight launch
 	FrameConstants* h_frame_constants_ = nullptr; // pinned source of the copies
-	uint32_t* d_work_counter_ = nullptr; // chunk counter of the persistent trace kernel, zeroed before each launch
+	uint32_t* d_work_counter_ = nullptr; // chunk counters of the persistent trace kernel: kTimingRing blocks, one per launch, zeroed before it
 	int compute_units_ = 0, blocks_per_cu_[2] = {0, 0};
 	// pinned staging (Scene.cpp:30-32)
 	int* h_positions_[2] = {nullptr, nullptr};

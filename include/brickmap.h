@@ -179,10 +179,12 @@ BM_API int bm_local_rows(const bm_frame_params* params);
  * Asynchronous with respect to the host.
  * Memory and ordering contract: accum_dev (and debug_dev) must be ordinary coarse-grained device memory
  * (hipMalloc / bm_buffer_alloc / a torch CUDA tensor): the wavefront mode accumulates with hardware float
- * atomics, which are not defined on fine-grained or host-mapped allocations.  A scene is not thread-safe, and
- * all frames of one scene must be issued on ONE stream at a time (each launch resets the scene's ticket
- * counters and updates accum_dev without atomics): wait for a frame before issuing the next one on a
- * different stream.  Width and height are limited to 65535, a shard to 2^32 pixels. */
+ * atomics, which are not defined on fine-grained or host-mapped allocations.  A scene is not thread-safe.
+ * Frames of one scene that accumulate into the SAME buffer may overlap in time (issued on different streams) only
+ * with BM_FLAG_SAMPLE_ITEMS, which adds samples with float atomics; without it a pixel is read when a lane takes it
+ * and written back when it is done, so such frames must be ordered (one stream, or events).  Every launch has its
+ * own ticket counters and constants (a ring of 256 launches in flight).  Scenes that stream bricks order uploads
+ * against ONE stream: keep their frames on one stream.  Width and height are limited to 65535, a shard to 2^32 pixels. */
 BM_API int bm_render_frame(bm_scene* scene, const bm_camera* camera, const bm_frame_params* params,
                            float* accum_dev, uint32_t* debug_dev, void* hip_stream);
 /* blit_onto_framebuffer (kernel.cu:348-364) into an offscreen float4 buffer: rgb/a, a=1, gamma 1/2.2 */

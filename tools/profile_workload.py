@@ -49,10 +49,11 @@ def main():
     bench_json = json.loads(line[-1])
     json.dump(bench_json, open(os.path.join(OUT, f"{tag}_bench_{workload}.json"), "w"), indent=1)
     print("bench:", bench_json["value"], bench_json["unit"], bench_json["ms_per_step"], "ms/step, roofline frac", bench_json["roofline"]["frac"])
-    # 2. kernel trace + stats of the same command
+    # 2. kernel trace + stats of the same command (without the untimed extra measurements of the N = 1 line, so that the
+    #    per-kernel averages are those of the warm-up + timed launches)
     d = f"/tmp/prof_{tag}_{workload}"
     shutil.rmtree(d, ignore_errors=True)
-    subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "p", "--"] + bench + steps + ["--no-cpu-baseline"],
+    subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", d, "-o", "p", "--"] + bench + steps + ["--no-cpu-baseline", "--no-extras"],
                    capture_output=True, text=True, cwd="/tmp", env=env)
     stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
     kernel_avg_ns = None
@@ -68,7 +69,7 @@ def main():
         d = f"/tmp/pmc_{tag}_{workload}_{i}"
         shutil.rmtree(d, ignore_errors=True)
         subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + group.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + bench +
-                       ["--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, cwd="/tmp", env=env)
+                       ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, cwd="/tmp", env=env)
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 if KERNEL in row["Kernel_Name"]:
