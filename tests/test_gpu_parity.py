@@ -727,3 +727,25 @@ def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
         assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
         assert out["config"]["spp_per_step"] == 8 and "roofline" in out and "cpu_baseline" not in out
         port += 1
+
+
+def test_frames_overlapping_on_two_streams(bm, orc, torch_cuda, scene256):
+    """Consecutive frames issued on two streams (what bench.py does at N = 1) may run at the same time: every launch has its
+    own ticket counters and constants, and with BM_FLAG_SAMPLE_ITEMS samples are added atomically, so the buffer ends up
+    with the same paths as the frames rendered one after the other."""
+    torch = torch_cuda
+    cam, _ = cameras(bm, orc, 256)
+    W, H, frames = 320, 200, 8
+    want = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    for i in range(frames):
+        scene256.render(cam, bm.FrameParams(W, H, spp=1, sample_base=i, max_bounces=3), want)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    got = torch.zeros_like(want)
+    torch.cuda.synchronize()
+    for i in range(frames):
+        scene256.render(cam, bm.FrameParams(W, H, spp=1, sample_base=i, max_bounces=3, flags=bm.BM_FLAG_SAMPLE_ITEMS), got, stream=streams[i % 4].cuda_stream)
+    torch.cuda.synchronize()
+    a, b = got.cpu().numpy(), want.cpu().numpy()
+    assert np.array_equal(a[..., 3], b[..., 3])  # terminated paths per pixel: exact in any order
+    np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=2e-6, atol=1e-9)
