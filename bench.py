@@ -7,9 +7,10 @@ A "step" is one launch of the path-trace kernel over this rank's shard of the wo
 (primary + up to max_bounces bounces, one shadow ray per hit) for every pixel of the shard, scene resident in HBM.
 
 N = 1 runs BASELINE.json configs[1] itself: 1920x1080, 1 spp, 4-bounce (MAX_BOUNCES = 3 -> 4 segments), 8x8x8
-superchunks, all bricks resident.  Consecutive steps are issued on two alternating HIP streams (`--pipeline 2`), so the
-next frame's workgroups take over the slots of the waves that have finished while the rest of the previous frame drains;
-samples are then added with float atomics.  The line also carries the one-stream figures (`pipeline.single_stream`).
+superchunks, all bricks resident.  Consecutive steps are issued on two alternating HIP streams (`--pipeline 2`, for
+every N), each with its own accumulation buffer, so the next frame's workgroups take over the slots of the waves that
+have finished while the rest of the previous frame drains.  The N = 1 line also carries the one-stream figures
+(`pipeline.single_stream`).
 
 N > 1 STRONG-scales one fixed job with the north-star decomposition: the same 1080p / 4-segment frame at
 MULTI_GPU_SPP = 8 samples per pixel, cut into interleaved 16-row bands (band b belongs to rank b % N); every rank traces
@@ -67,8 +68,10 @@ def main():
                     help="N > 1: strong = the fixed job (frame at --multi-gpu-spp samples) over N ranks; weak = N x spp samples in total")
     ap.add_argument("--multi-gpu-spp", type=int, default=8, help="samples per pixel of the strong-scaled job (N > 1)")
     ap.add_argument("--pipeline", type=int, default=2,
-                    help="N = 1, resident scene: consecutive steps are issued on this many alternating HIP streams, so that the next frame's "
-                         "workgroups start while the previous frame drains (accumulation with float atomics); 1 = one stream")
+                    help="resident scenes: consecutive steps are issued on this many alternating HIP streams (one accumulation buffer each), "
+                         "so that the next frame's workgroups start while the previous frame drains; 1 = one stream")
+    ap.add_argument("--verify", action="store_true",
+                    help="N > 1: after the timed region rank 0 renders every step unsharded and compares it with the gathered / reduced frame")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra measurements of the N = 1 line (one-stream figures, the 4-spp north-star shape): "
                          "used when the run is profiled, so that rocprofv3's per-kernel averages cover the timed launches")
@@ -143,12 +146,14 @@ def main():
             raise SystemExit("--schedule wavefront does not shard (replicas only): run it with --gpus 1")
         return bench_wavefront(args, bm, torch, np, scene, cam, accum, W, H, max_bounces, n_super, G, streaming, build_s)
 
-    # N = 1, everything resident: pipeline consecutive frames over `pipeline` streams.  A fifth of a 1-spp frame is the drain
-    # (waves working their last paths off); the next frame's workgroups fill the freed slots.  Two frames may
-    # then touch a pixel at the same time, so samples are added with float atomics (BM_FLAG_SAMPLE_ITEMS).
-    pipeline = max(1, args.pipeline) if (world == 1 and not streaming) else 1
-    streams = None  # chosen below, once the scene can render (HIP maps streams onto a few hardware queues: not every pair overlaps)
-    item_flag = bm.BM_FLAG_SAMPLE_ITEMS if (world > 1 or pipeline > 1) else 0  # (chunk, sample) work items + atomic accumulation
+    # Everything resident: pipeline consecutive frames over `pipeline` streams.  A fifth of a 1080p-sample frame is the drain
+    # (waves working their last paths off); the next frame's workgroups fill the freed slots.  Every stream
+    # has its OWN accumulation buffer (frame i adds into buffer i % pipeline), so no two frames in flight touch the same
+    # pixel record and the default, deterministic accumulation can be used; the image is the sum of the buffers.
+    pipeline = max(1, args.pipeline) if not streaming else 1
+    streams = None  # chosen below (HIP maps streams onto a few hardware queues: not every pair overlaps)
+    accums = [accum] + [torch.zeros_like(accum) for _ in range(pipeline - 1)]
+    item_flag = bm.BM_FLAG_SAMPLE_ITEMS if world > 1 else 0  # (chunk, sample) work items keep 1/N-of-the-pixels shards fed
 
     def params(step, flags=0):
         if by_rows:  # rank r owns the bands b with b % N == r and traces every sample of the step for them
@@ -183,16 +188,28 @@ def main():
                 best = (tc, combo)
         streams = [pool[i] for i in best[1]]
 
+    gathered = {}  # --verify: the last gathered frame of every accumulation buffer (rank 0)
+
+    def keep(step, frame):
+        if args.verify and frame is not None and step >= 0:
+            gathered[step % pipeline] = frame.clone()
+
     def one_step(step):
+        j = step % pipeline
         if streams is not None:
-            scene.render(cam, params(step), accum, stream=streams[step % pipeline].cuda_stream)
-            return accum
+            scene.render(cam, params(step), accums[j], stream=streams[j].cuda_stream)
+            if gatherer is not None:
+                keep(step - 1, gatherer.finish())  # frame step-1 is complete on rank 0 (while frame `step` is already running on the other stream)
+                streams[j].wait_stream(torch.cuda.current_stream())  # ... before the send / receive buffers are written again
+                with torch.cuda.stream(streams[j]):
+                    gatherer.start(accums[j])  # snapshot behind frame `step` on its stream + asynchronous gather of its packed bands
+            return accums[j]
         scene.render(cam, params(step), accum)
         if streaming:
             scene.process_load_queue()
         if gatherer is not None:
-            gatherer.finish()      # frame step-1 is complete on rank 0
-            gatherer.start(accum)  # snapshot + asynchronous gather of this frame's packed bands
+            keep(step - 1, gatherer.finish())  # frame step-1 is complete on rank 0
+            gatherer.start(accum)              # snapshot + asynchronous gather of this frame's packed bands
         return accum
 
     if streaming:  # reach streaming steady state before anything is timed
@@ -205,7 +222,7 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     if gatherer is not None:
-        gatherer.finish()
+        keep(args.warmup - 1, gatherer.finish())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -214,10 +231,14 @@ def main():
     for i in range(args.steps):
         one_step(args.warmup + i)
     if gatherer is not None:
-        gatherer.finish()  # the last frame's gather is inside the timed region
+        keep(args.warmup + args.steps - 1, gatherer.finish())  # the last frame's gather is inside the timed region
     if reducer is not None:
+        if streams is not None:
+            torch.cuda.synchronize()
+            for extra in accums[1:]:
+                accum.add_(extra)  # the image is the sum of the per-stream buffers
         reducer.start(accum)
-        reducer.finish()
+        reduced = reducer.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -229,9 +250,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- --verify: the frames rank 0 holds now must be the frames of one GPU rendering every sample of every step
+    verified = None
+    if args.verify and world > 1 and rank == 0:
+        want = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+        for i in range(args.warmup + args.steps):
+            scene.render(cam, bm.FrameParams(W, H, spp=spp_total, sample_base=i * spp_total, max_bounces=max_bounces), want)
+        torch.cuda.synchronize()
+        have = sum(gathered.values()) if by_rows else reduced
+        err = float((have.to(dev) - want).abs().max() / want.abs().max())
+        if not err < 1e-5:  # bit-identical paths; only the order of the float additions differs
+            raise SystemExit(f"--verify: the {world}-rank frame differs from the single-GPU frame (relative error {err:g})")
+        verified = {"frames": args.warmup + args.steps, "max_rel_err": err}
+
     # ---- the same steps on ONE stream with plain accumulation (the product's default call pattern), for the record
     single = None
-    if pipeline > 1 and not args.no_extras:
+    if pipeline > 1 and world == 1 and not args.no_extras:
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(args.steps):
@@ -328,8 +362,8 @@ def main():
         },
     }
     if pipeline > 1:
-        out["pipeline"] = {"streams": pipeline, "note": "consecutive steps on alternating streams, float-atomic accumulation; roofline uses each "
-                           "kernel's own HIP-event duration, which includes the time it shares the GPU with its neighbour",
+        out["pipeline"] = {"streams": pipeline, "note": "consecutive steps on alternating streams, one accumulation buffer per stream; roofline uses "
+                           "each kernel's own HIP-event duration, which includes the time it shares the GPU with its neighbour",
                            "frac_per_step": round(alg_bytes / args.steps / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
     if single is not None:
         single["roofline_frac"] = round(alg_bytes / args.steps / (single["kernel_ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
@@ -337,6 +371,8 @@ def main():
 
     if target4 is not None:
         out["north_star_4spp"] = target4
+    if verified is not None:
+        out["verified_against_single_gpu"] = verified
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, H, max_bounces, G, cam)
     print(json.dumps(out), flush=True)

@@ -706,7 +706,8 @@ def test_sample_items_mode_matches_pixel_items(bm, orc, torch_cuda, scene256):
 
 
 def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
-    """`bench.py --gpus 2` end to end -- row-band shards with (chunk, sample) work items, pipelined gather to rank 0,
+    """`bench.py --gpus 2` end to end -- row-band shards with (chunk, sample) work items, frames pipelined over two streams, pipelined gather to rank 0,
+    the gathered / reduced frames compared with one GPU rendering everything (--verify),
     max-over-ranks timing, one JSON line -- with both ranks on this GPU and gloo instead of RCCL (BM_BENCH_SHARE_GPU=1).
     The 8-GPU run itself is the driver's; this pins the code path it takes."""
     import json
@@ -717,15 +718,17 @@ def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for extra in ([], ["--decomposition", "samples"]):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "config1"] + extra
+               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", "config1", "--verify"] + extra
         env = dict(os.environ, BM_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(line) == 1, r.stdout[-1500:]
         out = json.loads(line[0])
-        assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
+        assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "strong"
         assert out["config"]["spp_per_step"] == 8 and "roofline" in out and "cpu_baseline" not in out
+        assert out["verified_against_single_gpu"]["frames"] == 5 and out["verified_against_single_gpu"]["max_rel_err"] < 1e-5
+        assert out["pipeline"]["streams"] == 2  # every rank overlaps consecutive frames on two streams
         port += 1
 
 
