@@ -513,7 +513,47 @@ def test_config3_like_streaming_lod_at_scale(bm, orc, torch_cuda):
     rows = bm.dist.shard_rows(H, 1, 11, 40)
     assert np.array_equal(dbg[rows], odbg[rows])
     assert_radiance(acc[rows], oacc[rows])
+    # ---- BASELINE config 4 at FULL size on this one GPU: 3840x2160, 16 spp, 8 segments, the same streamed world, as the
+    # 8 row-band shards bench.py --gpus 8 hands out ((chunk, sample) work items, float-atomic adds); the assembled frame is
+    # the frame of one launch tracing everything, and four of its rows are the oracle's
+    full_size_sharded_job(bm, orc, torch, scene, cam, ocam, w, 3840, 2160, spp=16, shards=8, oracle_row_groups=540)
     scene.close()
+
+
+def full_size_sharded_job(bm, orc, torch, scene, cam, ocam, oracle_world, W, H, spp, shards, oracle_row_groups, streamed=True):
+    """One multi-GPU job of BASELINE (configs 4 / 5) run shard by shard on this GPU; see the callers."""
+    band = bm.dist.DEFAULT_BAND_ROWS
+    whole = bm.FrameParams(W, H, spp=spp, max_bounces=7)
+    full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    for _ in range(64 if streamed else 1):  # streaming steady state for THIS frame (more samples touch more bricks)
+        full.zero_()
+        scene.render(cam, whole, full)
+        if not streamed or scene.process_load_queue() == 0:
+            break
+    else:
+        pytest.fail("no streaming steady state at full size")
+    dbg = torch.zeros((H, W, 8), dtype=torch.int32, device="cuda:0")
+    scene.render(cam, whole, torch.zeros_like(full), debug=dbg)  # hit records of the same frame (instrumented instantiation)
+    assembled = torch.zeros_like(full)
+    for r in range(shards):
+        p = bm.FrameParams(W, H, spp=spp, max_bounces=7, band_rows=band, shard_rank=r, shard_count=shards, flags=bm.BM_FLAG_SAMPLE_ITEMS)
+        packed = torch.zeros((bm.local_rows(p), W, 4), dtype=torch.float32, device="cuda:0")
+        scene.render(cam, p, packed)
+        rows = torch.as_tensor(bm.dist.shard_rows(H, band, r, shards), device="cuda:0", dtype=torch.long)
+        assembled.index_copy_(0, rows, packed)
+    torch.cuda.synchronize()
+    if streamed:
+        assert scene.process_load_queue() == 0  # the shards asked for nothing the whole frame had not
+    a, f = assembled.cpu().numpy(), full.cpu().numpy()
+    assert np.array_equal(a[..., 3], f[..., 3]) and float(f[..., 3].min()) == spp  # every path of every pixel ended, once
+    assert np.allclose(a[..., :3], f[..., :3], rtol=2e-5, atol=1e-7)  # same paths, the samples of a pixel added in another order
+    oacc, odbg, _, _ = oracle_world.render(ocam, orc.make_frame(W, H, spp=spp, max_bounces=7, band_rows=1, shard_rank=oracle_row_groups // 3,
+                                                                 shard_count=oracle_row_groups), threads=os.cpu_count() or 1)
+    rows = bm.dist.shard_rows(H, 1, oracle_row_groups // 3, oracle_row_groups)
+    rows_dev = torch.as_tensor(rows, device="cuda:0", dtype=torch.long)
+    assert np.array_equal(dbg[rows_dev].cpu().numpy().view(np.uint32), odbg[rows])
+    assert_radiance(f[rows], oacc[rows])
+    assert_radiance(a[rows], oacc[rows])
 
 
 def test_config5_like_lod_world_at_scale(bm, orc, torch_cuda):
@@ -557,6 +597,9 @@ def test_config5_like_lod_world_at_scale(bm, orc, torch_cuda):
     streamed = scene.info()
     assert 0 < streamed["resident_bricks"] < info["total_bricks"] // 8
     assert 64 * streamed["resident_bricks"] <= streamed["pool_bytes"] <= streamed["brick_bytes"] < 64 * info["total_bricks"] // 4
+    # ---- BASELINE config 5 at FULL size on this one GPU: 7680x4320, 32 spp, 8 segments (8.5 G nominal rays), streamed, as
+    # the 8 row-band shards of the 8-GPU job; assembled frame == one launch tracing everything; two rows are the oracle's
+    full_size_sharded_job(bm, orc, torch_cuda, scene, cam, ocam, w, 7680, 4320, spp=32, shards=8, oracle_row_groups=2160)
     scene.close()
 
 
