@@ -118,11 +118,17 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 
 	bool work_left = true;
 	constexpr uint32_t kCounters = BM_WORK_COUNTERS, kCounterStride = 32; // one 128-byte line per counter
-	int my_counter = static_cast<int>((blockIdx.x * 4u + (threadIdx.x >> 6)) % kCounters);
+	// (the wave index is the same in all 64 lanes; saying so keeps everything derived from it -- the counter in use, `work_left`,
+	// the loop's exit conditions -- in scalar registers and the scheduler loop's branches scalar)
+	int my_counter = static_cast<int>((blockIdx.x * 4u + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)))) % kCounters);
 	int counters_done = 0;
 	// hang guard only (NaN directions): no wave needs more scheduler rounds than this
-	long long rounds_left = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fc.spp) + 1) * (fc.max_bounces + 2) *
-							(2ll * sc.cells + sc.cells_height + 64);
+	const long long round_budget = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fc.spp) + 1) * (fc.max_bounces + 2) *
+								   (2ll * sc.cells + sc.cells_height + 64);
+	// (64-bit products are computed by the vector unit: bring the count back into scalar registers, or every test of it
+	// turns the scheduler loop's branches into exec-mask branches)
+	long long rounds_left = static_cast<long long>((static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(round_budget >> 32)))) << 32) |
+												   static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(round_budget))));
 	uint32_t runsA = 0, lanesA = 0, runsB = 0, lanesB = 0, runsC = 0, lanesC = 0, runsD = 0, lanesD = 0, runsJ = 0, lanesJ = 0; // wave-uniform scheduler statistics
 
 	unsigned long long cycA = 0, cycB = 0, cycC = 0, cycD = 0;
@@ -187,11 +193,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		const int nB = __popcll(__ballot(state == ST_CAND));
 		const int nC = __popcll(__ballot(state == ST_NEED || state == ST_CONN)); // shade / generate, and connect (same pass)
 		const int live = nA + nB + nC;
-		if (live == 0) {
-			if (!work_left || --rounds_left < 0) break;
-			continue; // everything idle but chunks remain (only pixels outside the image were handed out)
-		}
-		if (--rounds_left < 0) break;
+		--rounds_left;
+		if (rounds_left < 0 || (live == 0 && !work_left)) break;
+		// (live == 0 with chunks left: only pixels outside the image were handed out; the passes below find nothing to do)
 		// Policy: an expensive phase runs once a quarter of the live lanes wait for it, the cheap connect phase
 		// once an eighth does; otherwise the DDA keeps moving.  With no lane left in the DDA the largest group runs.
 		const int quorum = (live * BM_QUORUM_NUM + BM_QUORUM_DIV - 1) / BM_QUORUM_DIV;
