@@ -38,7 +38,7 @@ enum : int { P_GEN = 0, P_EXT_DONE = 1, P_SHD_DONE = 2, P_BOUNCE = 3 };
 enum : int { ST_IDLE = 4, ST_CONN = 5 };
 
 #ifndef BM_WAVES_PER_SIMD
-#define BM_WAVES_PER_SIMD 4
+#define BM_WAVES_PER_SIMD 5
 #endif
 #ifndef BM_WORK_COUNTERS
 #define BM_WORK_COUNTERS 8
