@@ -53,13 +53,6 @@ BM_JHD float jump_float(uint32_t u) {
 	return f;
 #endif
 }
-BM_JHD float jump_rcp(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-	return __builtin_amdgcn_rcpf(x); // ~1 ulp; the quotient below is corrected exactly
-#else
-	return x != 0.0f ? 1.0f / x : 0.0f; // (a zero increment belongs to an axis that cannot step; its quotient is masked)
-#endif
-}
 // product of two values below 2^24 (full-rate 24-bit multiplier on the device); the low 32 bits are what is used
 BM_JHD uint32_t jump_mul24(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -83,75 +76,91 @@ BM_JHD bool jump_possible(float tx, float ty, float tz) {
 	return jump_bits(m) - kJumpMinBits < kJumpMaxBits - kJumpMinBits;
 }
 
-// #{ j >= 0 : M + j*Q < thr }  for bit patterns of one binade (thr - M <= 2^23), Q >= 1; 0 when thr <= M.
-// The quotient is at most 255 for every axis that can step inside the jump (see dda_jump), so the fp32 estimate is
-// within 2^-13 of the true quotient and one exact integer correction settles it.
-BM_JHD uint32_t jump_count_below(uint32_t thr, uint32_t M, uint32_t Q, float rcpQ) {
-	const uint32_t a = thr - M - 1u; // garbage when thr <= M: masked at the end
-	// the estimate is biased upwards by 2^-12 (the quotient is below 2^8, its error below 2^-13): it is the true floor or
-	// one more, never less, so a single correction settles it
-	uint32_t q = static_cast<uint32_t>(static_cast<float>(a) * rcpQ + 0.000244140625f);
-	const int32_t rem = static_cast<int32_t>(a - jump_mul24(q, Q)); // q <= 2^9 here, Q <= 2^23
-	q -= rem < 0 ? 1u : 0u;
-	return thr > M ? q + 1u : 0u;
-}
+// ---- cost model behind the shape of this code (tools/ubench/valu_rates.hip, gfx950): plain float / integer add, sub, mul,
+// fma, and / or / xor, shift right issue in ~2.6 cycles per wave; compares (5.3), selects (4.9), min / max, conversions,
+// 24-bit multiplies, three-operand forms (~4.8) and the reciprocal (8.6) are the expensive ones.  So: 0 / -1 masks from
+// arithmetic shifts instead of compare + select, `x & mask` instead of `cond ? x : 0`, and no reciprocal at all.
 
-struct JumpAxis {
-	uint32_t M, Q; // bit pattern of tmax, per-step increment of the bit pattern inside the current binade
-	uint32_t E;    // bit pattern of tmax at the moment this axis takes its last allowed step
-	float rcpQ;
-};
-
-// Per-axis set-up.  e_bits = exponent field of the smallest tmax, C = 2^e, n = steps this axis may take (>= 1).
-BM_JHD JumpAxis jump_axis(float t, float d, uint32_t n, uint32_t e_bits, float C, float half_ulp) {
-	JumpAxis ax;
-	ax.M = jump_bits(t);
-	const float Ca = C + d;                    // rounds d to a multiple of ulp(C) -- the same rounding tmax + tdelta gets in this binade
-	uint32_t Q = jump_bits(Ca) - e_bits;
-	Q = Q < (1u << 23) ? Q : (1u << 23);       // tdelta >= 2^e: only the current tmax is inside the binade; keeps E below 2^32
-	const float r = d - (Ca - C);              // exact: the bits of tdelta below ulp(C)
-	const bool irregular = jump_fabs(r) == half_ulp && (ax.M & 1u); // tie on an odd mantissa: the next increment differs from the later ones
-	ax.Q = Q;
-	ax.rcpQ = jump_rcp(static_cast<float>(Q));
-	ax.E = ax.M + jump_mul24(irregular ? 0u : n - 1u, Q);
-	return ax;
+BM_JHD float jump_min3(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return __builtin_fminf(__builtin_fminf(a, b), c); // v_min3_f32 (no NaN reaches a jump: jump_possible)
+#else
+	float m = a < b ? a : b;
+	return m < c ? m : c;
+#endif
 }
+BM_JHD uint32_t jump_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 
 // Advance (tx, ty, tz) until one axis has taken n steps (exited the empty cube), or to the end of the current binade,
 // whichever comes first.  cx / cy / cz = steps taken per axis (at least one in total); last_axis = axis of the final
 // step (0 / 1 / 2) when the jump ended with a cube exit or an irregular step, and is only meaningful then -- a jump
 // that stops at a binade end is still inside the cube (every count < n).
-// Requires jump_possible(tx, ty, tz), 1 <= n <= 255, tdelta >= 0 finite.
+//
+// ix / iy / iz = |direction| per axis, i.e. 1 / tdelta up to rounding (tdelta = |1 / d|, voxel.cuh:180-187): the number of
+// steps an axis takes below a threshold is a quotient a / Q with Q = tdelta / ulp, estimated as a * (ulp * |d|) and
+// settled by one exact integer correction.  The estimate is within (a / Q) * (1 / Q + 2^-22) of the true quotient; the
+// quotient is below 255 (no axis takes n <= 255 steps before the jump ends) and Q >= 2^23 / (steps taken so far + 2)
+// for every axis that can still step -- tmax[a] <= (steps + 1) * tdelta[a] and the binade is that of the SMALLEST tmax --
+// so with at most 1026 cells per axis (bm_scene_create refuses larger worlds) the error is below 1/32: the estimate is
+// biased upwards by 1/16 and is then the true floor or one more, never less.
+//
+// Requires jump_possible(tx, ty, tz), n <= 255 (0 counts as 1), tdelta >= 0 finite.
 // Returns true when the jump ended with a final step (cube exit / irregular step), false when it stopped at the binade end.
-BM_JHD bool dda_jump(float& tx, float& ty, float& tz, float dx, float dy, float dz, uint32_t n, uint32_t& cx, uint32_t& cy, uint32_t& cz, int& last_axis) {
-	float m = tx < ty ? tx : ty;
-	m = m < tz ? m : tz;
+BM_JHD bool dda_jump(float& tx, float& ty, float& tz, float dx, float dy, float dz, float ix, float iy, float iz, uint32_t n, uint32_t& cx,
+					 uint32_t& cy, uint32_t& cz, int& last_axis) {
+	const float m = jump_min3(tx, ty, tz);
 	const uint32_t e_bits = jump_bits(m) & 0x7F800000u;
 	const uint32_t B = e_bits + (1u << 23); // bit pattern of 2^(e+1): an axis whose tmax is at or above it cannot step inside this jump
 	const float C = jump_float(e_bits);
+	const float ulp = jump_float(e_bits - (23u << 23));
 	const float half_ulp = jump_float(e_bits - (24u << 23));
-	const JumpAxis X = jump_axis(tx, dx, n, e_bits, C, half_ulp);
-	const JumpAxis Y = jump_axis(ty, dy, n, e_bits, C, half_ulp);
-	const JumpAxis Z = jump_axis(tz, dz, n, e_bits, C, half_ulp);
-	// which axis reaches its last allowed step first, in the reference's order (voxel.cuh:249-252 applied to E)
-	const bool mx = X.E < Y.E && X.E < Z.E;
-	const bool my = Y.E <= X.E && Y.E < Z.E;
-	const uint32_t E = mx ? X.E : (my ? Y.E : Z.E);
-	last_axis = mx ? 0 : (my ? 1 : 2);
-	// steps of axis b that come before-or-with the final step: tmax < E, or == E for an axis at least as late in the tie
-	// order as the exit axis (that includes the exit axis itself); nothing at or beyond the binade end
-	const uint32_t Ex = E + (mx ? 1u : 0u), Ey = E + ((mx || my) ? 1u : 0u), Ez = E + 1u;
-	const uint32_t thx = Ex < B ? Ex : B, thy = Ey < B ? Ey : B, thz = Ez < B ? Ez : B;
-	cx = jump_count_below(thx, X.M, X.Q, X.rcpQ);
-	cy = jump_count_below(thy, Y.M, Y.Q, Y.rcpQ);
-	cz = jump_count_below(thz, Z.M, Z.Q, Z.rcpQ);
-	// the last addition on every axis is a real one (it may leave the binade); the ones before it follow the recurrence
-	const float nx = jump_float(X.M + jump_mul24(cx - 1u, X.Q)) + dx; // (garbage for a count of 0: discarded)
-	tx = cx ? nx : tx;
-	const float ny = jump_float(Y.M + jump_mul24(cy - 1u, Y.Q)) + dy; // (garbage for a count of 0: discarded)
-	ty = cy ? ny : ty;
-	const float nz = jump_float(Z.M + jump_mul24(cz - 1u, Z.Q)) + dz; // (garbage for a count of 0: discarded)
-	tz = cz ? nz : tz;
+	const uint32_t k = n ? n - 1u : 0u; // steps before the last allowed one
+	const uint32_t Mx = jump_bits(tx), My = jump_bits(ty), Mz = jump_bits(tz);
+	// per axis: Q = increment of the bit pattern per step inside this binade (C + d rounds d to a multiple of ulp(C) -- the
+	// same rounding tmax + tdelta gets), capped at 2^23 (tdelta >= 2^e: only the current tmax is inside the binade; keeps
+	// every product below 2^32 and every factor below 2^24); r = the bits of tdelta below ulp(C), exact
+	const float Cx = C + dx, Cy = C + dy, Cz = C + dz;
+	const uint32_t Qx = jump_umin(jump_bits(Cx) - e_bits, 1u << 23), Qy = jump_umin(jump_bits(Cy) - e_bits, 1u << 23),
+				   Qz = jump_umin(jump_bits(Cz) - e_bits, 1u << 23);
+	const float rx = dx - (Cx - C), ry = dy - (Cy - C), rz = dz - (Cz - C);
+	uint32_t kx = k, ky = k, kz = k;
+	// a tie (r exactly half an ulp) on an odd mantissa: the next increment differs from the later ones -> one step only.
+	// Rare (tdelta needs a run of zero bits), so the wave branches around it.
+	const bool tie_x = jump_fabs(rx) == half_ulp, tie_y = jump_fabs(ry) == half_ulp, tie_z = jump_fabs(rz) == half_ulp;
+	if (tie_x | tie_y | tie_z) {
+		kx = (tie_x && (Mx & 1u)) ? 0u : k;
+		ky = (tie_y && (My & 1u)) ? 0u : k;
+		kz = (tie_z && (Mz & 1u)) ? 0u : k;
+	}
+	// bit pattern of tmax at the moment each axis takes its last allowed step; the earliest of them ends the jump, in the
+	// reference's order (voxel.cuh:249-252: at equal tmax z moves before y before x)
+	const uint32_t Ex = Mx + jump_mul24(kx, Qx), Ey = My + jump_mul24(ky, Qy), Ez = Mz + jump_mul24(kz, Qz);
+	const uint32_t E = jump_umin(jump_umin(Ex, Ey), Ez);
+	const uint32_t nz = jump_umin(Ez - E, 1u), ny = jump_umin(Ey - E, 1u); // 1: the axis is NOT the one that ends the jump at E
+	const uint32_t nyz = nz & ny;                                          // 1: x ends it
+	last_axis = static_cast<int>(2u - nz - nyz);
+	// steps of axis b that come before-or-with the final step: tmax < E, or == E for an axis that moves before the exit
+	// axis at equal tmax (that includes the exit axis itself); nothing at or beyond the binade end
+	const uint32_t thx = jump_umin(E + nyz, B), thy = jump_umin(E + nz, B), thz = jump_umin(E + 1u, B);
+	// count = #{ j >= 0 : M + j*Q < th } = floor((th - M - 1) / Q) + 1 when th > M, else 0
+	const float bias = 0.0625f;
+	// all-ones where the axis steps at all (th > M; both are bit patterns below 2^31), zero where it does not
+	const uint32_t vx = static_cast<uint32_t>(static_cast<int32_t>(Mx - thx) >> 31), vy = static_cast<uint32_t>(static_cast<int32_t>(My - thy) >> 31),
+				   vz = static_cast<uint32_t>(static_cast<int32_t>(Mz - thz) >> 31);
+	const uint32_t ax_ = (thx + ~Mx) & vx, ay_ = (thy + ~My) & vy, az_ = (thz + ~Mz) & vz; // th - M - 1, or 0 for an axis that does not step
+	uint32_t qx = static_cast<uint32_t>(static_cast<float>(ax_) * (ulp * ix) + bias);
+	uint32_t qy = static_cast<uint32_t>(static_cast<float>(ay_) * (ulp * iy) + bias);
+	uint32_t qz = static_cast<uint32_t>(static_cast<float>(az_) * (ulp * iz) + bias);
+	// exact correction: one less when the remainder is negative (the arithmetic shift yields the -1); q = steps before the last one
+	qx += static_cast<uint32_t>(static_cast<int32_t>(ax_ - jump_mul24(qx, Qx)) >> 31);
+	qy += static_cast<uint32_t>(static_cast<int32_t>(ay_ - jump_mul24(qy, Qy)) >> 31);
+	qz += static_cast<uint32_t>(static_cast<int32_t>(az_ - jump_mul24(qz, Qz)) >> 31);
+	cx = (qx + 1u) & vx; cy = (qy + 1u) & vy; cz = (qz + 1u) & vz;
+	// the last addition on every axis is a real one (it may leave the binade); the ones before it follow the recurrence.
+	// An axis that does not step adds +0 to its (positive) tmax.
+	tx = jump_float(Mx + jump_mul24(qx, Qx)) + jump_float(jump_bits(dx) & vx);
+	ty = jump_float(My + jump_mul24(qy, Qy)) + jump_float(jump_bits(dy) & vy);
+	tz = jump_float(Mz + jump_mul24(qz, Qz)) + jump_float(jump_bits(dz) & vz);
 	return E < B;
 }
 

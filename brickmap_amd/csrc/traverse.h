@@ -251,7 +251,10 @@ __device__ __forceinline__ int field_step(const DeviceScene& sc, RayState& r, Ta
 }
 
 // Cross the empty cube ahead of the current cell (or as much of it as the current binade of tmax allows) in one go.
-template <bool DBG>
+// DIR: RayState::d holds the ray direction (the fused kernel); otherwise |direction| is recovered from tdelta with the
+// hardware reciprocal (the queue kernels keep the direction in the queue record, not in the pooled walk state) -- it only
+// feeds a quotient estimate that is corrected exactly (jump.h).
+template <bool DBG, bool DIR = true>
 __device__ __forceinline__ int field_jump(const DeviceScene& sc, RayState& r, Tally& tally) {
 	uint32_t cx, cy, cz;
 	int axis;
@@ -259,7 +262,10 @@ __device__ __forceinline__ int field_jump(const DeviceScene& sc, RayState& r, Ta
 	const float dx = r.dx, dy = r.dy, dz = r.dz;
 	const int step_x = r.sx, step_y = r.stepy, step_z = r.stepz; // scalar copies, see field_step
 	const uint32_t n = r.cube & 0xFFu; // (a cell whose brick the ray just passed through has 0: one plain move, valid anywhere)
-	dda_jump(tx, ty, tz, dx, dy, dz, n ? n : 1u, cx, cy, cz, axis);
+	const float ix = DIR ? fabsf(r.d.x) : (dx > 0.f ? __builtin_amdgcn_rcpf(dx) : 0.f);
+	const float iy = DIR ? fabsf(r.d.y) : (dy > 0.f ? __builtin_amdgcn_rcpf(dy) : 0.f);
+	const float iz = DIR ? fabsf(r.d.z) : (dz > 0.f ? __builtin_amdgcn_rcpf(dz) : 0.f);
+	dda_jump(tx, ty, tz, dx, dy, dz, ix, iy, iz, n, cx, cy, cz, axis);
 	r.tx = tx; r.ty = ty; r.tz = tz;
 	// all three products fit 24-bit signed multiplies: counts <= 255, increments +-1 / +-2^11 / +-2^22
 	r.p += static_cast<uint32_t>(__mul24(static_cast<int>(cx), step_x) + __mul24(static_cast<int>(cy), step_y) + __mul24(static_cast<int>(cz), step_z));
@@ -294,7 +300,7 @@ __device__ __forceinline__ int walk_round(const DeviceScene& sc, RayState& r, in
 		for (int pass = 0; pass < BM_JUMP_PASSES; ++pass) {
 			if (DBG) { runs++; lanes += static_cast<uint32_t>(walkers); }
 			if (state == ST_JUMP || state == ST_OUTER) {
-				if (!(r.cube & kCubeNoJump)) state = field_jump<DBG>(sc, r, tally);
+				if (!(r.cube & kCubeNoJump)) state = field_jump<DBG, false>(sc, r, tally);
 				else state = field_step<DBG>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
 			}
 			// another pass right away while most of the walkers are still walking: keeps the rays of a wave together on their

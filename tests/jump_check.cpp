@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
 			s.d[i] = sgn * rdinv;
 		}
 		// walk; at random points try a jump with a random cube edge
-		const int walk = 1 + static_cast<int>(rnd() % 600);
+		const int walk = 1 + static_cast<int>(rnd() % (ray % 8 == 0 ? 3000 : 600)); // up to 3 x 1026 cells: the longest walk of a supported world
 		for (int k = 0; k < walk; ++k) {
 			if (rnd() % 4 == 0) {
 				if (!bm::jump_possible(s.t[0], s.t[1], s.t[2])) { skipped_pre++; }
@@ -70,7 +70,14 @@ int main(int argc, char** argv) {
 					float jt[3] = {s.t[0], s.t[1], s.t[2]};
 					uint32_t c[3];
 					int last = -1;
-					const bool exited = bm::dda_jump(jt[0], jt[1], jt[2], s.d[0], s.d[1], s.d[2], n, c[0], c[1], c[2], last);
+					// |direction| as the fused kernel passes it, or recovered from tdelta as the queue kernels do (perturbed by an ulp like a hardware reciprocal)
+					float inv[3];
+					const bool from_delta = rnd() % 2 == 0;
+					for (int i = 0; i < 3; ++i) {
+						inv[i] = from_delta ? (s.d[i] > 0.f ? 1.0f / s.d[i] : 0.f) : std::fabs(dir[i]);
+						if (from_delta && inv[i] > 0.f) inv[i] = std::nextafter(inv[i], (rnd() & 1) ? 0.f : 2.f * inv[i]);
+					}
+					const bool exited = bm::dda_jump(jt[0], jt[1], jt[2], s.d[0], s.d[1], s.d[2], inv[0], inv[1], inv[2], n, c[0], c[1], c[2], last);
 					Dda r = s;
 					uint32_t rc[3] = {0, 0, 0};
 					int rlast = -1;
