@@ -7,10 +7,11 @@ A "step" is one launch of the path-trace kernel over this rank's shard of the wo
 (primary + up to max_bounces bounces, one shadow ray per hit) for every pixel of the shard, scene resident in HBM.
 
 N = 1 runs BASELINE.json configs[1] itself: 1920x1080, 1 spp, 4-bounce (MAX_BOUNCES = 3 -> 4 segments), 8x8x8
-superchunks, all bricks resident.  Consecutive steps are issued on two alternating HIP streams (`--pipeline 2`, for
-every N), each with its own accumulation buffer, so the next frame's workgroups take over the slots of the waves that
-have finished while the rest of the previous frame drains.  The N = 1 line also carries the one-stream figures
-(`pipeline.single_stream`).
+superchunks, all bricks resident, one launch per step on one stream.  `--pipeline 2` issues consecutive steps on two
+alternating HIP streams, each with its own accumulation buffer, so that the next frame's workgroups take over the slots
+of the waves that have finished while the rest of the previous frame drains (more frames per second, but every
+kernel's own duration then includes the time it shares the GPU); the N = 1 line reports that mode next to the headline
+(`pipelined`), never as `value`.
 
 N > 1 STRONG-scales one fixed job with the north-star decomposition: the same 1080p / 4-segment frame at
 MULTI_GPU_SPP = 8 samples per pixel, cut into interleaved 16-row bands (band b belongs to rank b % N); every rank traces
@@ -67,13 +68,13 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the fixed job (frame at --multi-gpu-spp samples) over N ranks; weak = N x spp samples in total")
     ap.add_argument("--multi-gpu-spp", type=int, default=8, help="samples per pixel of the strong-scaled job (N > 1)")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=1,
                     help="resident scenes: consecutive steps are issued on this many alternating HIP streams (one accumulation buffer each), "
                          "so that the next frame's workgroups start while the previous frame drains; 1 = one stream")
     ap.add_argument("--verify", action="store_true",
                     help="N > 1: after the timed region rank 0 renders every step unsharded and compares it with the gathered / reduced frame")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the untimed extra measurements of the N = 1 line (one-stream figures, the 4-spp north-star shape): "
+                    help="skip the untimed extra measurements of the N = 1 line (two-stream figures, the 4-spp north-star shape): "
                          "used when the run is profiled, so that rocprofv3's per-kernel averages cover the timed launches")
     ap.add_argument("--streaming-mode", choices=["overlapped", "blocking"], default="overlapped",
                     help="streaming workloads: overlapped = two request rings, the host never waits for the GPU; blocking = the reference's order")
@@ -167,14 +168,14 @@ def main():
     gatherer = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev) if by_rows else None
     reducer = bm.dist.FrameReducer(H, W, device=dev) if (world > 1 and not by_rows) else None
 
-    if pipeline > 1:
-        # Which streams run concurrently is a property of how the runtime maps them onto hardware queues; pick the group of
-        # `pipeline` streams (out of a few more) on which a short burst of frames finishes first.
-        # (probed with torch's spin kernel, one thread busy for ~0.2 ms: no frame is rendered for this)
+    def pick_streams(count):
+        """Which streams run concurrently is a property of how the runtime maps them onto hardware queues; pick the group of
+        `count` streams (out of a few more) on which a short burst of work finishes first (probed with torch's spin
+        kernel, one thread busy for ~0.2 ms: no frame is rendered for this)."""
         import itertools
-        pool = [torch.cuda.Stream() for _ in range(pipeline + 3)]
+        pool = [torch.cuda.Stream() for _ in range(count + 3)]
         best = None
-        for combo in itertools.combinations(range(len(pool)), pipeline):
+        for combo in itertools.combinations(range(len(pool)), count):
             tc = 0.0
             for rep in range(3):
                 torch.cuda.synchronize()
@@ -186,7 +187,10 @@ def main():
                 tc = (time.perf_counter() - t_c) if rep == 0 else min(tc, time.perf_counter() - t_c)
             if best is None or tc < best[0] * 0.9:
                 best = (tc, combo)
-        streams = [pool[i] for i in best[1]]
+        return [pool[i] for i in best[1]]
+
+    if pipeline > 1:
+        streams = pick_streams(pipeline)
 
     gathered = {}  # --verify: the last gathered frame of every accumulation buffer (rank 0)
 
@@ -263,17 +267,22 @@ def main():
             raise SystemExit(f"--verify: the {world}-rank frame differs from the single-GPU frame (relative error {err:g})")
         verified = {"frames": args.warmup + args.steps, "max_rel_err": err}
 
-    # ---- the same steps on ONE stream with plain accumulation (the product's default call pattern), for the record
-    single = None
-    if pipeline > 1 and world == 1 and not args.no_extras:
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            scene.render(cam, bm.FrameParams(W, H, spp=spp_rank, sample_base=(args.warmup + i) * spp_total, max_bounces=max_bounces), accum)
-        torch.cuda.synchronize()
-        e1 = time.perf_counter() - t1
-        single = {"ms_per_step": round(e1 / args.steps * 1e3, 4), "kernel_ms_avg": round(float(np.mean(scene.render_times(args.steps))), 4),
-                  "value": round(W * H * spp_total * segments * args.steps / e1 / 1e6, 3)}
+    # ---- the same steps pipelined over two streams (one accumulation buffer each), for the record: N = 1 / resident only
+    pipelined = None
+    if pipeline == 1 and world == 1 and not streaming and not args.no_extras:
+        two = pick_streams(2)
+        bufs = [accum, torch.zeros_like(accum)]
+        for rep in range(2):  # the first repetition warms the second stream up
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                scene.render(cam, params(args.warmup + i), bufs[i % 2], stream=two[i % 2].cuda_stream)
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t1
+        pipelined = {"streams": 2, "ms_per_step": round(e1 / args.steps * 1e3, 4), "value": round(W * H * spp_total * segments * args.steps / e1 / 1e6, 3),
+                     "kernel_ms_avg": round(float(np.mean(scene.render_times(args.steps))), 4),
+                     "note": "consecutive steps on two alternating streams, one accumulation buffer per stream: the next frame's workgroups start "
+                             "while the previous frame drains; a kernel's own duration then includes the time it shares the GPU"}
 
     # ---- algorithmic bytes of exactly the timed launches, from the instrumented kernel variant (not timed)
     scene.counters_reset()
@@ -365,9 +374,9 @@ def main():
         out["pipeline"] = {"streams": pipeline, "note": "consecutive steps on alternating streams, one accumulation buffer per stream; roofline uses "
                            "each kernel's own HIP-event duration, which includes the time it shares the GPU with its neighbour",
                            "frac_per_step": round(alg_bytes / args.steps / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
-    if single is not None:
-        single["roofline_frac"] = round(alg_bytes / args.steps / (single["kernel_ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-        out["pipeline"]["single_stream"] = single
+    if pipelined is not None:
+        pipelined["frac_per_step"] = round(alg_bytes / args.steps / (pipelined["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        out["pipelined"] = pipelined
 
     if target4 is not None:
         out["north_star_4spp"] = target4

@@ -761,7 +761,7 @@ def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for extra in ([], ["--decomposition", "samples"]):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", "config1", "--verify"] + extra
+               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", "config1", "--verify", "--pipeline", "2"] + extra
         env = dict(os.environ, BM_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
