@@ -40,6 +40,9 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_WAVES_PER_SIMD
 #define BM_WAVES_PER_SIMD 5
 #endif
+#ifndef BM_ITEM_LANES
+#define BM_ITEM_LANES 4 // pixels handed out per ticket: a 4x1 row of a 4x4 chunk (16 = whole chunks: 2.5 % slower, a refill then leaves up to 15 idle lanes empty)
+#endif
 #ifndef BM_WORK_COUNTERS
 #define BM_WORK_COUNTERS 8
 #endif
@@ -88,7 +91,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	// multi-GPU frame); samples of one pixel then run on different lanes and are added with float atomics like the
 	// reference does (kernel.cu:319-322,341-343), so radiance is equal up to summation order.
 	const bool sample_items = (fc.flags & 4u) != 0u; // BM_FLAG_SAMPLE_ITEMS
-	const uint32_t items_per_chunk = sample_items ? static_cast<uint32_t>(fc.spp > 0 ? fc.spp : 1) : 1u;
+	constexpr uint32_t kParts = 16u / BM_ITEM_LANES; // tickets per chunk and sample
+	const uint32_t items_per_chunk = (sample_items ? static_cast<uint32_t>(fc.spp > 0 ? fc.spp : 1) : 1u) * kParts;
 
 	// per-pixel state
 	uint32_t xy = 0;          // x | y << 16
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	unsigned long long t_dry = 0ull; // when this wave found the ticket counters empty (BM_TIMED): the rest of its life is the drain
 
 	for (;;) {
-		// ---- refill: hand pixels to idle lanes, 16 (one 4x4 chunk) at a time
+		// ---- refill: hand pixels to idle lanes, BM_ITEM_LANES at a time (consecutive tickets walk through a 4x4 chunk)
 		const unsigned long long idle = __ballot(state == ST_IDLE);
 		const int nI = __popcll(idle);
 		if (work_left && nI >= BM_REFILL_MIN) {
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			// long.  The chunk sequence is therefore dealt to kCounters interleaved counters (8x8-pixel groups of four
 			// chunks, group g on counter g % kCounters, each counter on its own cache line): every counter still sweeps
 			// the image top-down, so concurrently running waves keep working on neighbouring rows of the image.
-			const int want = nI >> 4;
+			const int want = nI / BM_ITEM_LANES;
 			uint32_t base = 0;
 			if (lane == 0) base = atomicAdd(work_counter + my_counter * kCounterStride, static_cast<uint32_t>(want));
 			base = __builtin_amdgcn_readfirstlane(base);
@@ -159,17 +163,19 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				if (++counters_done >= static_cast<int>(kCounters)) { work_left = false; if (BM_TIMED) t_dry = __builtin_amdgcn_s_memtime(); }
 			}
 			const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
-			if (state == ST_IDLE && rank < want * 16) {
-				const uint32_t item = base + static_cast<uint32_t>(rank >> 4);
-				const uint32_t ticket = item / items_per_chunk, item_sample = item - ticket * items_per_chunk;
+			if (state == ST_IDLE && rank < want * BM_ITEM_LANES) {
+				const uint32_t item = base + static_cast<uint32_t>(rank / BM_ITEM_LANES);
+				const uint32_t ticket = item / items_per_chunk, item_sub = item - ticket * items_per_chunk;
+				const uint32_t item_sample = item_sub / kParts, part = item_sub % kParts; // (kParts == 1: part 0)
 				const uint32_t chunk = ((ticket >> 2) * kCounters + counter_now) * 4u + (ticket & 3u);
 				if (item < my_tickets && chunk < total_chunks) {
 					const uint32_t tile = chunk >> 4, k = chunk & 15u;
 					const int tile_x = static_cast<int>(tile % static_cast<uint32_t>(fc.tiles_x));
 					const int tile_y = static_cast<int>(tile / static_cast<uint32_t>(fc.tiles_x));
 					const int cx = static_cast<int>((k & 1u) | ((k >> 1) & 2u)), cy = static_cast<int>(((k >> 1) & 1u) | ((k >> 2) & 2u));
-					const int x = tile_x * 16 + cx * 4 + (rank & 3);
-					const int ly = tile_y * 16 + cy * 4 + ((rank >> 2) & 3); // row inside this shard's packed buffer
+					const uint32_t q = part * BM_ITEM_LANES + (static_cast<uint32_t>(rank) % BM_ITEM_LANES); // pixel of the 4x4 chunk
+					const int x = tile_x * 16 + cx * 4 + static_cast<int>(q & 3u);
+					const int ly = tile_y * 16 + cy * 4 + static_cast<int>(q >> 2); // row inside this shard's packed buffer
 					const int y = ((ly / fc.band_rows) * fc.shard_count + fc.shard_rank) * fc.band_rows + ly % fc.band_rows;
 					if (x < fc.width && ly < fc.local_rows && y < fc.height) {
 						p = static_cast<uint32_t>(y) * W + static_cast<uint32_t>(x);
