@@ -8,8 +8,8 @@
 // operation (IEEE fp32, no contraction; see DESIGN.md "Numeric contract") so that hits are
 // bit-identical to the CPU oracle.
 //
-// Launch geometry: persistent 256-thread workgroups (compute units x resident blocks); waves pull 4x4-pixel chunks
-// from interleaved ticket counters and schedule their lanes' work in phases (see trace_paths below).
+// Launch geometry: persistent 256-thread workgroups (compute units x resident blocks); waves pull rows of 4x4-pixel
+// chunks from interleaved ticket counters and schedule their lanes' work in phases (see trace_paths below).
 // The device functions shared with the queue-based schedule (wavefront.hip) live in traverse.h.
 #include "traverse.h"
 
@@ -19,8 +19,8 @@ namespace bm {
 //
 // Work distribution: the shard's pixels are cut into 4x4-pixel chunks (ordered so that four consecutive
 // chunks form an 8x8 block and sixteen a 16x16 tile).  Waves are persistent: whenever 16 or more of a
-// wave's lanes have no pixel, the wave takes that many chunks from a global counter (one atomic per
-// refill) and hands one pixel to each idle lane.  A lane traces ALL samples of its pixel, in order, before
+// wave's lanes have no pixel, the wave takes that many pixels, in 4x1 rows of consecutive chunks, from a global
+// counter (one atomic per refill) and hands one pixel to each idle lane.  A lane traces ALL samples of its pixel, in order, before
 // it takes another one, so each pixel's accumulation order is fixed (sample by sample, event by event).
 //
 // Path state machine per lane:
