@@ -1,0 +1,39 @@
+"""Guard rails for the production kernel's compiled shape (CPU only: hipcc cross-compiles gfx950 without a GPU).
+
+bm::trace_paths<false> is bound by vector-instruction issue at 5 waves per SIMD.  Two things silently cost
+10 % or more and have both happened: a register budget above 96 VGPRs (one wave per SIMD less, or spills), and the backend
+linearising the scheduler loop's scalar branches again, which keeps every lane's state in two register sets and copies
+one onto the other around every pass (a few hundred extra v_mov; a small change to the loop's control flow is enough).
+"""
+import collections
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "brickmap_amd", "csrc")
+KERNEL = "_ZN2bm11trace_pathsILb0E"
+
+
+def test_production_kernel_keeps_its_register_budget_and_its_shape():
+    subprocess.check_call(["make", "-s", "-C", CSRC, "asm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    usage = open(os.path.join(CSRC, "build", "resource_usage.txt")).read()
+    block = usage[usage.index(KERNEL):]
+    block = block[:block.index("Function Name", 10)] if "Function Name" in block[10:] else block
+
+    def field(name):
+        return int(re.search(name + r": (\d+)", block).group(1))
+
+    assert field("VGPRs") <= 96, "more than 96 VGPRs: 4 waves per SIMD instead of 5"
+    assert field("VGPRs Spill") == 0 and field(r"ScratchSize \[bytes/lane\]") == 0
+    assert field(r"Occupancy \[waves/SIMD\]") == 5
+    lines = open(os.path.join(CSRC, "build", "trace-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL) and ":" in l)
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    ops = collections.Counter(l.split(";")[0].split()[0] for l in lines[start:end] if l.startswith("\t") and l.split(";")[0].strip())
+    valu = sum(c for o, c in ops.items() if o.startswith("v_"))
+    movs = sum(c for o, c in ops.items() if o.startswith("v_mov_b"))
+    packed = sum(c for o, c in ops.items() if o.startswith("v_pk_"))
+    assert movs <= 260, f"{movs} register copies in {valu} VALU instructions: the scheduler loop was structurized again (tools/isa_movs.py)"
+    assert packed == 0, "packed fp32 operations: SLP vectorisation is back (they cost two plain operations each and pair registers)"
+    assert valu <= 2100, f"{valu} VALU instructions"
