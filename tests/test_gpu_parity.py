@@ -749,7 +749,8 @@ def test_sample_items_mode_matches_pixel_items(bm, orc, torch_cuda, scene256):
 
 
 def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
-    """`bench.py --gpus 2` end to end -- row-band shards with (chunk, sample) work items, frames pipelined over two streams, pipelined gather to rank 0,
+    """`bench.py --gpus 2` end to end -- row-band shards with (chunk, sample) work items, pipelined gather to rank 0 (the driver's
+    command line, then with every rank's frames overlapping on two streams, then the sample decomposition),
     the gathered / reduced frames compared with one GPU rendering everything (--verify),
     max-over-ranks timing, one JSON line -- with both ranks on this GPU and gloo instead of RCCL (BM_BENCH_SHARE_GPU=1).
     The 8-GPU run itself is the driver's; this pins the code path it takes."""
@@ -759,9 +760,9 @@ def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
     import sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ([], ["--decomposition", "samples"]):
+    for extra in ([], ["--pipeline", "2"], ["--pipeline", "2", "--decomposition", "samples"]):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", "config1", "--verify", "--pipeline", "2"] + extra
+               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", "config1", "--verify"] + extra
         env = dict(os.environ, BM_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
@@ -771,12 +772,12 @@ def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
         assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "strong"
         assert out["config"]["spp_per_step"] == 8 and "roofline" in out and "cpu_baseline" not in out
         assert out["verified_against_single_gpu"]["frames"] == 5 and out["verified_against_single_gpu"]["max_rel_err"] < 1e-5
-        assert out["pipeline"]["streams"] == 2  # every rank overlaps consecutive frames on two streams
+        assert ("pipeline" in out) == ("--pipeline" in extra) and out.get("pipeline", {"streams": 2})["streams"] == 2
         port += 1
 
 
 def test_frames_overlapping_on_two_streams(bm, orc, torch_cuda, scene256):
-    """Consecutive frames issued on two streams (what bench.py does at N = 1) may run at the same time: every launch has its
+    """Consecutive frames issued on two streams (what bench.py --pipeline 2 does) may run at the same time: every launch has its
     own ticket counters and constants, and with BM_FLAG_SAMPLE_ITEMS samples are added atomically, so the buffer ends up
     with the same paths as the frames rendered one after the other."""
     torch = torch_cuda
