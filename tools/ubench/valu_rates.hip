@@ -119,6 +119,30 @@ KERNEL(k_mul_f32_sgpr, "v_mul_f32 %0, s10, %0\n")
 KERNEL(k_add_u32_sgpr, "v_add_u32 %4, s10, %4\n")
 KERNEL(k_add_u32_inl, "v_add_u32 %4, 5, %4\n")
 
+
+// the same v_add_f32 / v_bfe_u32 loops with part of the wave masked off (an ordinary divergent `if`, so that the compiler
+// keeps EXEC consistent): does an instruction cost less when half of its 64 lanes are inactive?
+#define KERNEL_EXEC(name, ASM, COND)                                                                        \
+	__global__ __launch_bounds__(256) void name(float* out, float a, float b) {                             \
+		float v0 = a + threadIdx.x, v1 = b, v2 = a * 2, v3 = b * 3;                                        \
+		unsigned u0 = threadIdx.x, u1 = blockIdx.x + 7;                                                    \
+		unsigned long long w = threadIdx.x * 0x100000001ull;                                               \
+		const unsigned lane = threadIdx.x & 63u;                                                           \
+		if (COND) {                                                                                        \
+			for (int i = 0; i < ITER; ++i) { REP16(asm volatile(ASM : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(u0), "+v"(u1), "+v"(w) : : "vcc", "scc", "s10", "s11");) } \
+		}                                                                                                  \
+		out[blockIdx.x * 256 + threadIdx.x] = v0 + v1 + v2 + v3 + u0 + u1 + (float)w;                      \
+	}
+KERNEL_EXEC(k_add_f32_lo32, "v_add_f32 %0, %1, %0\n", lane < 32u)
+KERNEL_EXEC(k_add_f32_lo16, "v_add_f32 %0, %1, %0\n", lane < 16u)
+KERNEL_EXEC(k_add_f32_even, "v_add_f32 %0, %1, %0\n", (lane & 1u) == 0u)
+KERNEL_EXEC(k_bfe_lo32, "v_bfe_u32 %4, %4, 2, 9\n", lane < 32u)
+KERNEL_EXEC(k_bfe_lo16, "v_bfe_u32 %4, %4, 2, 9\n", lane < 16u)
+KERNEL_EXEC(k_bfe_one, "v_bfe_u32 %4, %4, 2, 9\n", lane == 0u)
+KERNEL_EXEC(k_cmp_lo32, "v_cmp_lt_f32 vcc, %0, %1\n", lane < 32u)
+KERNEL_EXEC(k_rcp_lo32, "v_rcp_f32 %0, %0\n", lane < 32u)
+KERNEL_EXEC(k_rcp_lo16, "v_rcp_f32 %0, %0\n", lane < 16u)
+
 template <typename K>
 static void run(const char* name, K kernel, int per_iter, float* out, int cus) {
 	for (int waves : {4, 8}) {
@@ -158,6 +182,7 @@ int main() {
 	RUN(k_mbcnt,1); RUN(k_dpp_mov,1); RUN(k_dpp_add,1); RUN(k_sdwa,1); RUN(k_cmp_lt_i32,1); RUN(k_cmp_class,1); RUN(k_cmpx,1); RUN(k_cnd_vcc_dep,4); RUN(k_add_mul_mix,2); RUN(k_add_and_mix,2);
 	RUN(k_salu_add,1); RUN(k_salu_valu_mix,2); RUN(k_salu_bfe_mix,2); RUN(k_sub_lit,1); RUN(k_add_lit_f32,1); RUN(k_mul_legacy,1); RUN(k_med3,1); RUN(k_fma_lit,1); RUN(k_cvt_i32_f32,1);
 	RUN(k_ffbh,1); RUN(k_ffbl,1); RUN(k_not,1); RUN(k_bfrev,1); RUN(k_readfirst,1); RUN(k_lshl64,1); RUN(k_add_u32_e64,1); RUN(k_add_f32_e64,1); RUN(k_add_f32_abs,1);
+	RUN(k_add_f32_lo32,1); RUN(k_add_f32_lo16,1); RUN(k_add_f32_even,1); RUN(k_bfe_lo32,1); RUN(k_bfe_lo16,1); RUN(k_bfe_one,1); RUN(k_cmp_lo32,1); RUN(k_rcp_lo32,1); RUN(k_rcp_lo16,1);
 	RUN(k_mul_f32_sgpr,1); RUN(k_add_u32_sgpr,1); RUN(k_add_u32_inl,1);
 	return 0;
 }
