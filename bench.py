@@ -270,19 +270,23 @@ def main():
     # ---- the same steps pipelined over two streams (one accumulation buffer each), for the record: N = 1 / resident only
     pipelined = None
     if pipeline == 1 and world == 1 and not streaming and not args.no_extras:
-        two = pick_streams(2)
-        bufs = [accum, torch.zeros_like(accum)]
-        for rep in range(2):  # the first repetition warms the second stream up
+        try:  # an extra: whatever goes wrong here must not cost the headline measurement above
+            two = pick_streams(2)
+            bufs = [accum, torch.zeros_like(accum)]
+            for rep in range(2):  # the first repetition warms the second stream up
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    scene.render(cam, params(args.warmup + i), bufs[i % 2], stream=two[i % 2].cuda_stream)
+                torch.cuda.synchronize()
+                e1 = time.perf_counter() - t1
+            pipelined = {"streams": 2, "ms_per_step": round(e1 / args.steps * 1e3, 4), "value": round(W * H * spp_total * segments * args.steps / e1 / 1e6, 3),
+                         "kernel_ms_avg": round(float(np.mean(scene.render_times(args.steps))), 4),
+                         "note": "consecutive steps on two alternating streams, one accumulation buffer per stream: the next frame's workgroups start "
+                                 "while the previous frame drains; a kernel's own duration then includes the time it shares the GPU"}
+        except Exception as e:  # noqa: BLE001
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                scene.render(cam, params(args.warmup + i), bufs[i % 2], stream=two[i % 2].cuda_stream)
-            torch.cuda.synchronize()
-            e1 = time.perf_counter() - t1
-        pipelined = {"streams": 2, "ms_per_step": round(e1 / args.steps * 1e3, 4), "value": round(W * H * spp_total * segments * args.steps / e1 / 1e6, 3),
-                     "kernel_ms_avg": round(float(np.mean(scene.render_times(args.steps))), 4),
-                     "note": "consecutive steps on two alternating streams, one accumulation buffer per stream: the next frame's workgroups start "
-                             "while the previous frame drains; a kernel's own duration then includes the time it shares the GPU"}
+            pipelined = {"error": repr(e)}
 
     # ---- algorithmic bytes of exactly the timed launches, from the instrumented kernel variant (not timed)
     scene.counters_reset()
@@ -375,7 +379,8 @@ def main():
                            "each kernel's own HIP-event duration, which includes the time it shares the GPU with its neighbour",
                            "frac_per_step": round(alg_bytes / args.steps / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
     if pipelined is not None:
-        pipelined["frac_per_step"] = round(alg_bytes / args.steps / (pipelined["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+        if "ms_per_step" in pipelined:
+            pipelined["frac_per_step"] = round(alg_bytes / args.steps / (pipelined["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         out["pipelined"] = pipelined
 
     if target4 is not None:
