@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		const int nJ = __popcll(__ballot(state == ST_JUMP));
 		const int nA = __popcll(__ballot(state == ST_OUTER)) + nJ; // lanes walking the brick grid, cell by cell or cube by cube
 		const int nB = __popcll(__ballot(state == ST_CAND));
-		const int nC = __popcll(__ballot(state == ST_NEED || state == ST_CONN)); // shade / generate, and connect (same pass)
+		const int nC = __popcll(__ballot(state == ST_NEED) | __ballot(state == ST_CONN)); // shade / generate, and connect (same pass)
 		const int live = nA + nB + nC;
 		--rounds_left;
 		if (rounds_left < 0 || (live == 0 && !work_left)) break;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						state = (st == ST_NEED && shadow) ? ST_CONN : st;
 					}
 					if (BM_JUMP_PASSES > 1) { // another pass right away while most of the walkers are still walking (saves a scheduler round)
-						const int still = __popcll(__ballot(state == ST_JUMP || state == ST_OUTER));
+						const int still = __popcll(__ballot(state == ST_JUMP) | __ballot(state == ST_OUTER));
 						if (still * BM_JUMP_KEEP_DIV < walkers * BM_JUMP_KEEP_NUM || still == 0) break;
 						walkers = still;
 					}
