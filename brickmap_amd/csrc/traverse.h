@@ -577,7 +577,11 @@ __device__ __forceinline__ f3 bounce_direction(f3 n, uint32_t& seed) {
 	const float r2s = sqrtf(r2);
 	// computeOrthonormalBasisNaive (kernel.cu:76-84)
 	f3 u = fabs(static_cast<double>(n.x)) > .9 ? mk(0.0f, 1.0f, 0.0f) : mk(1.0f, 0.0f, 0.0f);
-	u = normalize(cross(u, n));
+	// cross(u, n) of a grid normal is already a unit axis vector: dot = 1, 1 / sqrt(1) = 1, v * 1 = v -- the square root and
+	// the division are only executed for the odd normal that is not axis-aligned (the identity is exact for any unit dot)
+	u = cross(u, n);
+	const float uu = dot(u, u);
+	if (uu != 1.0f) u = u * (1.0f / sqrtf(uu));
 	const f3 v = cross(n, u);
 	float sn, cs;
 	det_sincos(r1, sn, cs);
