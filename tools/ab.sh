@@ -3,8 +3,9 @@
 cmd=$1; shift
 cp brickmap_amd/libbrickmap_hip.so /tmp/lib_orig.so
 for v in "$@"; do
-  cp scratch/lib_$v.so brickmap_amd/libbrickmap_hip.so
   echo "== $v"
+  if [ ! -f scratch/lib_$v.so ]; then echo "(no scratch/lib_$v.so: skipped)"; continue; fi
+  cp scratch/lib_$v.so brickmap_amd/libbrickmap_hip.so
   eval "$cmd"
 done
 cp /tmp/lib_orig.so brickmap_amd/libbrickmap_hip.so
