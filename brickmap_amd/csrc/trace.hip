@@ -43,6 +43,21 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_ITEM_LANES
 #define BM_ITEM_LANES 4 // pixels handed out per ticket: a 4x1 row of a 4x4 chunk (16 = whole chunks: 2.5 % slower, a refill then leaves up to 15 idle lanes empty)
 #endif
+// Wave priorities (s_setprio) per pass: a wave in a walk or candidate pass -- short, and ending in a dependent load -- issues
+// before a wave in the long arithmetic of a shade pass, which fills the gaps: 1.169 -> 1.118 ms on config 2 (any of
+// walk / candidate / shade = 1/2/0, 2/3/0, 1/3/0, 2/3/1 within 0.5 %; shade highest: 1.157, all equal: no change).
+#ifndef BM_PRIO
+#define BM_PRIO 1
+#endif
+#ifndef BM_PRIO_A
+#define BM_PRIO_A 1
+#endif
+#ifndef BM_PRIO_B
+#define BM_PRIO_B 2
+#endif
+#ifndef BM_PRIO_C
+#define BM_PRIO_C 0
+#endif
 #ifndef BM_WORK_COUNTERS
 #define BM_WORK_COUNTERS 8
 #endif
@@ -214,6 +229,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 
 		const unsigned long long t_phase = BM_TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
 		if (phase == 2) {
+			if (BM_PRIO) __builtin_amdgcn_s_setprio(BM_PRIO_C);
 			if (BM_TIMED) {
 				const int n_conn = __popcll(__ballot(state == ST_CONN));
 				runsC++; lanesC += nC - n_conn;
@@ -360,6 +376,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				}
 			}
 		} else if (phase == 1) {
+			if (BM_PRIO) __builtin_amdgcn_s_setprio(BM_PRIO_B);
 			if (BM_TIMED) { runsB++; lanesB += nB; }
 			// ================= phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask DDA, streaming request)
 			if (state == ST_CAND) {
@@ -378,6 +395,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			// ST_OUTER lanes are close to the surface.  With enough jumpers in the wave every walking lane takes the jump
 			// pass (a cube of edge 1-3 is crossed just the same, and a jump with n = 1 is exactly one move, valid in any
 			// cell); otherwise the lanes near the surface make a few single moves and the jumpers wait for company.
+			if (BM_PRIO) __builtin_amdgcn_s_setprio(BM_PRIO_A);
 			const int nO = nA - nJ;
 			if (nJ * BM_JUMP_RATIO >= nO) {
 				int walkers = nA;
