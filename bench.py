@@ -19,7 +19,10 @@ all 8 samples of its rows into a packed float4 buffer (work items = (4x4 chunk, 
 the persistent waves stay fed on 1/N of the pixels), and the packed bands are gathered to rank 0 over RCCL/xGMI
 (brickmap_amd/dist.py FrameGatherer: grouped send/recv, 33 MB / N per peer per step).  The gather of step i overlaps the
 tracing of step i+1; every gather, including the last, completes inside the timed region.  Rates are per nominal ray,
-so the N = 1 line (1 spp) and the N > 1 lines (8 spp over N ranks) are directly comparable.
+but the N = 1 line is a DIFFERENT work shape (1 spp, pixel items; its end-of-frame drain is not amortised over samples,
+and coherent neighbouring samples run ~20 % faster per ray), so a scaling efficiency must not be computed against it:
+every N > 1 line carries `same_job_single_gpu` (rank 0 renders the line's own 8-spp job unsharded, untimed) and the
+N = 1 line carries the same figure as `multi_gpu_job_on_one_gpu` -- that is the denominator.
 `--decomposition samples` keeps the alternative cut (every rank the full frame with its own samples, ONE sum-reduction
 after the last step -- the buffers are additive), `--scaling weak` makes the job grow with N (N spp in total).
 
@@ -100,8 +103,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # BM_BENCH_FORCE_DIST=1 (the 1-rank RCCL dry run of tests/test_gpu_dist.py): take the multi-GPU code path -- process group
+    # on the "nccl" backend, row-band shard, (chunk, sample) work items, FrameGatherer / FrameReducer collectives on device
+    # tensors, barrier, max-over-ranks reduction -- with a single rank, so that everything except the second rank has run
+    multi = world > 1 or os.environ.get("BM_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -111,17 +119,17 @@ def main():
     W, H, spp, max_bounces, n_super, streaming = workload(args.workload)
     G = 128 * n_super
     segments = max_bounces + 1
-    by_rows = world > 1 and args.decomposition == "rows"
+    by_rows = multi and args.decomposition == "rows"
     # samples per pixel of one whole-job step, and of this rank's launch
-    if world == 1:
+    if not multi:
         spp_total = spp
     elif args.scaling == "strong":
         spp_total = max(args.multi_gpu_spp, 1) if args.workload == "config2" else spp * 8  # configs 4 / 5 name their totals (2 x 8, 4 x 8)
     else:
         spp_total = spp * world
-    if world > 1 and not by_rows and spp_total % world:
+    if multi and not by_rows and spp_total % world:
         raise SystemExit(f"--decomposition samples needs spp_total ({spp_total}) divisible by the number of ranks")
-    spp_rank = spp_total if (by_rows or world == 1) else spp_total // world
+    spp_rank = spp_total if (by_rows or not multi) else spp_total // world
     band = bm.dist.DEFAULT_BAND_ROWS
 
     # ---- scene replica on this GPU (world build is CPU plumbing and is not timed)
@@ -154,7 +162,7 @@ def main():
     pipeline = max(1, args.pipeline) if not streaming else 1
     streams = None  # chosen below (HIP maps streams onto a few hardware queues: not every pair overlaps)
     accums = [accum] + [torch.zeros_like(accum) for _ in range(pipeline - 1)]
-    item_flag = bm.BM_FLAG_SAMPLE_ITEMS if world > 1 else 0  # (chunk, sample) work items keep 1/N-of-the-pixels shards fed
+    item_flag = bm.BM_FLAG_SAMPLE_ITEMS if multi else 0  # (chunk, sample) work items keep 1/N-of-the-pixels shards fed
 
     def params(step, flags=0):
         if by_rows:  # rank r owns the bands b with b % N == r and traces every sample of the step for them
@@ -165,8 +173,8 @@ def main():
 
     # rows: the gather of frame i runs on RCCL's stream while frame i+1 is being traced (one gather in flight);
     # samples: ONE sum-reduction after the last step (the per-rank buffers are additive)
-    gatherer = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev) if by_rows else None
-    reducer = bm.dist.FrameReducer(H, W, device=dev) if (world > 1 and not by_rows) else None
+    gatherer = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev, force_collective=True) if by_rows else None
+    reducer = bm.dist.FrameReducer(H, W, device=dev, force_collective=True) if (multi and not by_rows) else None
 
     def pick_streams(count):
         """Which streams run concurrently is a property of how the runtime maps them onto hardware queues; pick the group of
@@ -228,7 +236,7 @@ def main():
     if gatherer is not None:
         keep(args.warmup - 1, gatherer.finish())
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
@@ -244,19 +252,19 @@ def main():
         reducer.start(accum)
         reduced = reducer.finish()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     kernel_ms = scene.render_times(args.steps)  # HIP events on the launch stream, one pair per launch
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- --verify: the frames rank 0 holds now must be the frames of one GPU rendering every sample of every step
     verified = None
-    if args.verify and world > 1 and rank == 0:
+    if args.verify and multi and rank == 0:
         want = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
         for i in range(args.warmup + args.steps):
             scene.render(cam, bm.FrameParams(W, H, spp=spp_total, sample_base=i * spp_total, max_bounces=max_bounces), want)
@@ -269,7 +277,7 @@ def main():
 
     # ---- the same steps pipelined over two streams (one accumulation buffer each), for the record: N = 1 / resident only
     pipelined = None
-    if pipeline == 1 and world == 1 and not streaming and not args.no_extras:
+    if pipeline == 1 and not multi and not streaming and not args.no_extras:
         try:  # an extra: whatever goes wrong here must not cost the headline measurement above
             two = pick_streams(2)
             bufs = [accum, torch.zeros_like(accum)]
@@ -306,7 +314,7 @@ def main():
     # ---- the north-star target shape (BASELINE.json: "1080p, 4 spp, 4-bounce"), N = 1 / config 2 only, reported next to the
     # headline, never as `value`: the same frame at 4 samples per pixel with (chunk, sample) work items
     target4 = None
-    if world == 1 and args.workload == "config2" and not streaming and not args.no_extras:
+    if not multi and args.workload == "config2" and not streaming and not args.no_extras:
         n4 = 5
         p4 = lambda i, flags=0: bm.FrameParams(W, H, spp=4, sample_base=1000 + 4 * i, max_bounces=max_bounces, flags=flags | bm.BM_FLAG_SAMPLE_ITEMS)
         for i in range(2):
@@ -326,8 +334,34 @@ def main():
                    "Mrays_s": round(W * H * 4 * segments / s4 / 1e6, 1), "kernel_ms_avg": round(k4 * 1e3, 4),
                    "roofline_frac": round(b4 / k4 / 1e9 / HBM_PEAK_GBS, 5)}
 
+    # ---- the denominator of a scaling efficiency: the N > 1 lines strong-scale ONE fixed job (the frame at spp_total samples,
+    # (chunk, sample) work items); rank 0 renders exactly that job unsharded on its GPU, untimed, so that value(N) can be
+    # compared with the single-GPU time of ITS OWN job and not with the N = 1 line's 1-spp frame (whose end-of-frame drain
+    # is not amortised over samples).  The N = 1 line carries the same measurement for the default 8-spp job.
+    same_job = None
+    job_spp = spp_total if multi else (max(args.multi_gpu_spp, 1) if args.workload == "config2" else spp * 8)
+    if rank == 0 and not streaming and not args.no_extras:
+        try:
+            whole = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+            pj = lambda i: bm.FrameParams(W, H, spp=job_spp, sample_base=5000 + i * job_spp, max_bounces=max_bounces, flags=bm.BM_FLAG_SAMPLE_ITEMS)
+            nj = 3
+            scene.render(cam, pj(0), whole)
+            torch.cuda.synchronize()
+            tj = time.perf_counter()
+            for i in range(nj):
+                scene.render(cam, pj(1 + i), whole)
+            torch.cuda.synchronize()
+            sj = (time.perf_counter() - tj) / nj
+            same_job = {"workload": f"{W}x{H}, {job_spp} spp, {segments} segments/path, (chunk, sample) work items, unsharded on one GPU",
+                        "ms_per_step": round(sj * 1e3, 4), "Mrays_s": round(W * H * job_spp * segments / sj / 1e6, 1),
+                        "kernel_ms_avg": round(float(np.mean(scene.render_times(nj))), 4)}
+            del whole
+        except Exception as e:  # noqa: BLE001 -- an extra: must not cost the headline measurement
+            torch.cuda.synchronize()
+            same_job = {"error": repr(e)}
+
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
@@ -340,7 +374,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": args.scaling if world > 1 else "strong",
+        "scaling": args.scaling if multi else "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic (SimplexNoise terrain built on the CPU by the product generator; canonical xorshift RNG streams)",
@@ -387,10 +421,12 @@ def main():
         out["north_star_4spp"] = target4
     if verified is not None:
         out["verified_against_single_gpu"] = verified
-    if world == 1 and not args.no_cpu_baseline:
+    if same_job is not None:
+        out["same_job_single_gpu" if multi else "multi_gpu_job_on_one_gpu"] = same_job
+    if not multi and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, H, max_bounces, G, cam)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

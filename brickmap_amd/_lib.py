@@ -44,7 +44,8 @@ class bm_scene_info(C.Structure):
                 ("generated", C.c_int32), ("on_device", C.c_int32),
                 ("total_bricks", C.c_uint64), ("resident_bricks", C.c_uint64),
                 ("index_bytes", C.c_uint64), ("brick_bytes", C.c_uint64),
-                ("pool_bytes", C.c_uint64), ("cube_field_bytes", C.c_uint64)]
+                ("pool_bytes", C.c_uint64), ("cube_field_bytes", C.c_uint64),
+                ("arena_growths", C.c_uint64), ("arena_copy_growths", C.c_uint64), ("arena_virtual", C.c_int32), ("failed", C.c_int32)]
 
 
 COUNTER_NAMES = ("index_loads", "brick_tests", "byte_tests", "voxel_steps", "extend_rays",

@@ -106,15 +106,17 @@ BM_JHD uint32_t jump_umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 //
 // Requires jump_possible(tx, ty, tz), n <= 255 (0 counts as 1), tdelta >= 0 finite.
 // Returns true when the jump ended with a final step (cube exit / irregular step), false when it stopped at the binade end.
-BM_JHD bool dda_jump(float& tx, float& ty, float& tz, float dx, float dy, float dz, float ix, float iy, float iz, uint32_t n, uint32_t& cx,
-					 uint32_t& cy, uint32_t& cz, int& last_axis) {
+// bud_x / bud_y / bud_z: the step budget per axis (dda_jump below gives every axis the cube edge n; a jump that CONTINUES after a
+// binade stop hands each axis what is left of it, n - steps already taken, see field_jump).
+BM_JHD bool dda_jump3(float& tx, float& ty, float& tz, float dx, float dy, float dz, float ix, float iy, float iz, uint32_t bud_x, uint32_t bud_y, uint32_t bud_z,
+					  uint32_t& cx, uint32_t& cy, uint32_t& cz, int& last_axis) {
 	const float m = jump_min3(tx, ty, tz);
 	const uint32_t e_bits = jump_bits(m) & 0x7F800000u;
 	const uint32_t B = e_bits + (1u << 23); // bit pattern of 2^(e+1): an axis whose tmax is at or above it cannot step inside this jump
 	const float C = jump_float(e_bits);
 	const float ulp = jump_float(e_bits - (23u << 23));
 	const float half_ulp = jump_float(e_bits - (24u << 23));
-	const uint32_t k = n ? n - 1u : 0u; // steps before the last allowed one
+	const uint32_t k0x = bud_x ? bud_x - 1u : 0u, k0y = bud_y ? bud_y - 1u : 0u, k0z = bud_z ? bud_z - 1u : 0u; // steps before the last allowed one
 	const uint32_t Mx = jump_bits(tx), My = jump_bits(ty), Mz = jump_bits(tz);
 	// per axis: Q = increment of the bit pattern per step inside this binade (C + d rounds d to a multiple of ulp(C) -- the
 	// same rounding tmax + tdelta gets), capped at 2^23 (tdelta >= 2^e: only the current tmax is inside the binade; keeps
@@ -123,14 +125,14 @@ BM_JHD bool dda_jump(float& tx, float& ty, float& tz, float dx, float dy, float 
 	const uint32_t Qx = jump_umin(jump_bits(Cx) - e_bits, 1u << 23), Qy = jump_umin(jump_bits(Cy) - e_bits, 1u << 23),
 				   Qz = jump_umin(jump_bits(Cz) - e_bits, 1u << 23);
 	const float rx = dx - (Cx - C), ry = dy - (Cy - C), rz = dz - (Cz - C);
-	uint32_t kx = k, ky = k, kz = k;
+	uint32_t kx = k0x, ky = k0y, kz = k0z;
 	// a tie (r exactly half an ulp) on an odd mantissa: the next increment differs from the later ones -> one step only.
 	// Rare (tdelta needs a run of zero bits), so the wave branches around it.
 	const bool tie_x = jump_fabs(rx) == half_ulp, tie_y = jump_fabs(ry) == half_ulp, tie_z = jump_fabs(rz) == half_ulp;
 	if (tie_x | tie_y | tie_z) {
-		kx = (tie_x && (Mx & 1u)) ? 0u : k;
-		ky = (tie_y && (My & 1u)) ? 0u : k;
-		kz = (tie_z && (Mz & 1u)) ? 0u : k;
+		kx = (tie_x && (Mx & 1u)) ? 0u : k0x;
+		ky = (tie_y && (My & 1u)) ? 0u : k0y;
+		kz = (tie_z && (Mz & 1u)) ? 0u : k0z;
 	}
 	// bit pattern of tmax at the moment each axis takes its last allowed step; the earliest of them ends the jump, in the
 	// reference's order (voxel.cuh:249-252: at equal tmax z moves before y before x)
@@ -162,6 +164,11 @@ BM_JHD bool dda_jump(float& tx, float& ty, float& tz, float dx, float dy, float 
 	ty = jump_float(My + jump_mul24(qy, Qy)) + jump_float(jump_bits(dy) & vy);
 	tz = jump_float(Mz + jump_mul24(qz, Qz)) + jump_float(jump_bits(dz) & vz);
 	return E < B;
+}
+
+BM_JHD bool dda_jump(float& tx, float& ty, float& tz, float dx, float dy, float dz, float ix, float iy, float iz, uint32_t n, uint32_t& cx,
+					 uint32_t& cy, uint32_t& cz, int& last_axis) {
+	return dda_jump3(tx, ty, tz, dx, dy, dz, ix, iy, iz, n, n, n, cx, cy, cz, last_axis);
 }
 
 } // namespace bm

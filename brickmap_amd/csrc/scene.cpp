@@ -12,6 +12,10 @@
 
 #include "kernels.h"
 
+#ifndef BM_FIELD_BLOCKED
+#define BM_FIELD_BLOCKED 0
+#endif
+
 namespace bm {
 
 // ---------------------------------------------------------------- errors
@@ -127,7 +131,7 @@ Scene::~Scene() {
 		if (d_load_count_[r]) hipFree(d_load_count_[r]);
 	}
 	if (ev_snapshot_) hipEventDestroy(ev_snapshot_);
-	if (ev_frame_done_) hipEventDestroy(ev_frame_done_);
+	drop_frame_streams();
 	if (h_bricks_) hipHostFree(h_bricks_);
 	if (h_indices_) hipHostFree(h_indices_);
 	if (h_moves_) hipHostFree(h_moves_);
@@ -170,7 +174,6 @@ int Scene::init(int grid_size, int grid_height) {
 	}
 	BM_HIP(hipEventCreateWithFlags(&ev_upload_, hipEventDisableTiming));
 	BM_HIP(hipEventCreateWithFlags(&ev_snapshot_, hipEventDisableTiming));
-	BM_HIP(hipEventCreateWithFlags(&ev_frame_done_, hipEventDisableTiming));
 	for (int r = 0; r < 2; ++r) {
 		BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_count_[r]), sizeof(uint32_t), hipHostMallocDefault));
 		BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_load_count_[r]), sizeof(uint32_t)));
@@ -273,7 +276,7 @@ int Scene::set_queue_capacity(int cap) {
 void Scene::free_device() {
 	if (d_index_grid_) hipFree(d_index_grid_);
 	if (d_pool_base_) hipFree(d_pool_base_);
-	if (d_arena_) hipFree(d_arena_);
+	arena_close();
 	if (d_cube_field_) hipFree(d_cube_field_);
 	d_cube_field_ = nullptr;
 	d_index_grid_ = d_arena_ = d_pool_base_ = nullptr;
@@ -289,10 +292,109 @@ void Scene::arena_reset() {
 	freed_this_batch_.clear();
 }
 
-// Grow the arena to at least `bricks` (doubling), keeping what it holds.  Synchronises the device: frames in flight may
-// still read the old allocation, and the copy must see every upload.  Rare: log2(resident bricks) times per scene.
+// ---- the arena's address range.  Reserved once per world for the worst case -- every pool is a power of two >= its
+// supercell's brick count, and a pool that doubles its way up leaves regions of every smaller size behind (reused only by
+// pools of that size) -- i.e. below 4 x the world's bricks + 32 per supercell; address space costs nothing.
+int Scene::arena_open(uint64_t max_bricks) {
+	arena_close();
+	int vmm = 0;
+	if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, device_) != hipSuccess) vmm = 0;
+	if (const char* e = std::getenv("BM_ARENA_VMM")) vmm = vmm && std::atoi(e) != 0; // experiment knob: 0 = reallocate + copy
+	if (!vmm) { (void)hipGetLastError(); arena_virtual_ = false; return 0; }
+	hipMemAllocationProp prop{};
+	prop.type = hipMemAllocationTypePinned;
+	prop.location.type = hipMemLocationTypeDevice;
+	prop.location.id = device_;
+	size_t gran = 0;
+	BM_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+	if (gran == 0) gran = 2u << 20;
+	arena_granularity_ = gran;
+	uint64_t bytes = std::min<uint64_t>(max_bricks, (1ull << 32) - 1) * sizeof(Brick);
+	bytes = (std::max<uint64_t>(bytes, 1ull << 22) + gran - 1) / gran * gran;
+	void* va = nullptr;
+	BM_HIP(hipMemAddressReserve(&va, bytes, 0, nullptr, 0));
+	d_arena_ = static_cast<uint32_t*>(va);
+	arena_va_bytes_ = bytes;
+	arena_virtual_ = true;
+	arena_capacity_ = 0;
+	view_.brick_arena = d_arena_;
+	return 0;
+}
+
+int Scene::arena_unmap_all() {
+	for (const ArenaChunk& c : arena_chunks_) {
+		BM_HIP(hipMemUnmap(reinterpret_cast<char*>(d_arena_) + c.offset, c.bytes));
+		BM_HIP(hipMemRelease(c.handle));
+	}
+	arena_chunks_.clear();
+	arena_capacity_ = 0;
+	return 0;
+}
+
+void Scene::arena_close() {
+	if (arena_virtual_) {
+		(void)arena_unmap_all();
+		if (d_arena_) (void)hipMemAddressFree(d_arena_, arena_va_bytes_);
+	} else if (d_arena_) {
+		(void)hipFree(d_arena_);
+	}
+	d_arena_ = nullptr;
+	arena_virtual_ = false;
+	arena_va_bytes_ = 0;
+	arena_capacity_ = 0;
+	arena_chunks_.clear();
+}
+
+// Make the arena at least `bricks` large, keeping what it holds.  Virtual arena: map one more physical chunk behind the
+// mapped part (the mapped size doubles) -- no copy, no synchronisation, nothing moves, so frames in flight and upload
+// batches already queued are not disturbed (the reference grows one pool at a time with a blocking cudaMemcpy,
+// Scene.cpp:242-247).  exact: (re)size an EMPTY arena to fit a known residency (callers have synchronised the device).
 int Scene::arena_reserve(uint64_t bricks, bool exact) {
 	if (bricks <= arena_capacity_ && !(exact && arena_top_ == 0 && arena_capacity_ > 2 * std::max<uint64_t>(bricks, 1ull << 16))) return 0;
+	if (bricks >= (1ull << 32)) { set_error("brick arena would exceed 2^32 bricks"); return BM_EINVAL; }
+	if (arena_virtual_) {
+		const size_t gran = arena_granularity_;
+		auto round_up = [gran](uint64_t b) { return (b + gran - 1) / gran * gran; };
+		uint64_t want_bytes;
+		if (exact && arena_top_ == 0) {
+			if (int e = arena_unmap_all()) return e;
+			want_bytes = round_up(std::max<uint64_t>(bricks, 1ull << 16) * sizeof(Brick));
+		} else {
+			want_bytes = round_up(std::max<uint64_t>(arena_capacity_, 1ull << 16) * sizeof(Brick)); // 4 MiB to start with
+			while (want_bytes < bricks * sizeof(Brick)) want_bytes *= 2;
+		}
+		if (want_bytes > arena_va_bytes_) want_bytes = arena_va_bytes_;
+		if (want_bytes < bricks * sizeof(Brick)) { set_error("brick arena: reserved address range exhausted"); return BM_ESTATE; }
+		const size_t have = static_cast<size_t>(arena_capacity_) * sizeof(Brick);
+		if (want_bytes > have) {
+			hipMemAllocationProp prop{};
+			prop.type = hipMemAllocationTypePinned;
+			prop.location.type = hipMemLocationTypeDevice;
+			prop.location.id = device_;
+			ArenaChunk c{};
+			c.offset = have;
+			c.bytes = want_bytes - have;
+			BM_HIP(hipMemCreate(&c.handle, c.bytes, &prop, 0));
+			char* at = reinterpret_cast<char*>(d_arena_) + c.offset;
+			if (hipError_t e = hipMemMap(at, c.bytes, 0, c.handle, 0); e != hipSuccess) { (void)hipMemRelease(c.handle); return hip_fail(e, "hipMemMap", __FILE__, __LINE__); }
+			hipMemAccessDesc access{};
+			access.location = prop.location;
+			access.flags = hipMemAccessFlagsProtReadWrite;
+			// access is (re)declared for the WHOLE mapped range, from the base: on this runtime (ROCm 7.2) hipMemSetAccess on a
+			// chunk at an offset fails sporadically with "invalid argument" when the chunks differ in size
+			// (tools/ubench/vmm_probe2.hip: 33 of 144 growths; 0 of 144 this way, with kernels in flight over the range)
+			if (hipError_t e = hipMemSetAccess(d_arena_, want_bytes, &access, 1); e != hipSuccess) {
+				(void)hipMemUnmap(at, c.bytes); (void)hipMemRelease(c.handle);
+				return hip_fail(e, "hipMemSetAccess", __FILE__, __LINE__);
+			}
+			arena_chunks_.push_back(c);
+			if (arena_capacity_ > 0) arena_growths_++;
+			arena_capacity_ = want_bytes / sizeof(Brick);
+		}
+		return 0;
+	}
+	// ---- no virtual memory management on this device: reallocate + copy.  Synchronises the device: frames in flight may
+	// still read the old allocation, and the copy must see every upload.
 	uint64_t cap = bricks;
 	if (!exact) { // growth by residency: double
 		cap = std::max<uint64_t>(arena_capacity_, 1ull << 16); // 4 MiB to start with
@@ -304,7 +406,10 @@ int Scene::arena_reserve(uint64_t bricks, bool exact) {
 	BM_HIP(hipDeviceSynchronize());
 	uint32_t* fresh = nullptr;
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&fresh), cap * sizeof(Brick)));
-	if (d_arena_ && arena_top_ > 0) BM_HIP(hipMemcpy(fresh, d_arena_, arena_top_ * sizeof(Brick), hipMemcpyDeviceToDevice));
+	if (d_arena_ && arena_top_ > 0) {
+		BM_HIP(hipMemcpy(fresh, d_arena_, arena_top_ * sizeof(Brick), hipMemcpyDeviceToDevice));
+		arena_growths_++; arena_copy_growths_++;
+	}
 	if (d_arena_) BM_HIP(hipFree(d_arena_));
 	d_arena_ = fresh;
 	arena_capacity_ = cap;
@@ -354,17 +459,42 @@ int Scene::allocate_device() {
 	view_.index_grid = d_index_grid_;
 	view_.pool_base = d_pool_base_;
 	view_.brick_arena = nullptr;
+	if (int e = arena_open(4 * run + 32ull * static_cast<uint64_t>(d.supercells) + (1ull << 16))) return e;
 	{ // octant cube field: what the walk reads instead of index words while it crosses empty space
 		std::vector<uint8_t> field;
 		world.build_cube_field(field, 8);
+		const int cfx = d.cells + 2;
+#if BM_FIELD_BLOCKED
+		{ // experiment: 4x4x4-cell blocks of 64 bytes (one L2 sector) instead of rows; traverse.h field_lookup has the addressing
+			const int nbx = d.cells / 4 + 2, nbz = d.cells_height / 4 + 2;
+			const size_t bplane = static_cast<size_t>(nbx) * nbx * nbz * 64, rplane = field.size() / 8;
+			std::vector<uint8_t> blocked(bplane * 8, 255);
+			for (int o = 0; o < 8; ++o)
+				for (int z = 0; z < d.cells_height + 2; ++z)
+					for (int y = 0; y < cfx; ++y)
+						for (int x = 0; x < cfx; ++x) {
+							const int fx = x + 15, fy = y + 15, fz = z + 15; // the packed cell's biased fields
+							const size_t b = (static_cast<size_t>((fz >> 2) - 3) * nbx + ((fy >> 2) - 3)) * nbx + ((fx >> 2) - 3);
+							blocked[bplane * o + b * 64 + (fz & 3) * 16 + (fy & 3) * 4 + (fx & 3)] = field[rplane * o + (static_cast<size_t>(z) * cfx + y) * cfx + x];
+						}
+			field.swap(blocked);
+			BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cube_field_), field.size()));
+			BM_HIP(hipMemcpy(d_cube_field_, field.data(), field.size(), hipMemcpyHostToDevice));
+			view_.cf_x = nbx;
+			view_.cf_xy = nbx * nbx;
+			view_.cf_plane = static_cast<uint32_t>(bplane);
+			view_.cube_field = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(d_cube_field_) - static_cast<uintptr_t>(3) * 64 * (1 + nbx + nbx * nbx));
+			cube_field_bytes_ = field.size();
+		}
+#else
 		BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cube_field_), field.size()));
 		BM_HIP(hipMemcpy(d_cube_field_, field.data(), field.size(), hipMemcpyHostToDevice));
-		const int cfx = d.cells + 2;
 		view_.cf_x = cfx;
 		view_.cf_xy = cfx * cfx;
 		view_.cf_plane = static_cast<uint32_t>(field.size() / 8);
 		view_.cube_field = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(d_cube_field_) - static_cast<uintptr_t>(15) * (1 + cfx + cfx * cfx));
 		cube_field_bytes_ = field.size();
+#endif
 	}
 	view_.cells = d.cells;
 	view_.cells_height = d.cells_height;
@@ -389,6 +519,10 @@ int Scene::generate_supercell(int sx, int sy, int sz) {
 		set_error("supercell coordinates out of range");
 		return BM_EINVAL;
 	}
+	// Once the world is on the device its pools hold bricks in request order and the index words name those slots:
+	// rebuilding a host supercell would reset its slot counter under them (the regenerated content is identical anyway --
+	// the terrain is a pure function of the coordinates).  The reference never calls it after generate() either.
+	if (on_device_) { set_error("bm_scene_generate_supercell: the scene is on the device (call it before bm_scene_generate)"); return BM_ESTATE; }
 	world.generate_supercell(sx, sy, sz);
 	return 0;
 }
@@ -428,7 +562,10 @@ int Scene::reset_residency() {
 	view_.load_queue = d_load_queue_[0];
 	view_.load_queue_count = d_load_count_[0];
 	resident_bricks_ = 0;
-	upload_pending_ = false;
+	staging_busy_ = false;
+	failed_ = false;
+	upload_seq_ = 0;
+	for (FrameStream& f : frame_streams_) f.upload_seen = 0;
 	return 0;
 }
 
@@ -464,8 +601,64 @@ int Scene::preload_all() {
 	view_.load_queue = d_load_queue_[0];
 	view_.load_queue_count = d_load_count_[0];
 	resident_bricks_ = total_bricks_;
-	upload_pending_ = false;
+	staging_busy_ = false;
+	failed_ = false;
+	upload_seq_ = 0;
+	for (FrameStream& f : frame_streams_) f.upload_seen = 0;
 	return 0;
+}
+
+// ---------------------------------------------------------------- frames vs. uploads
+// A frame on `stream` must see every brick batch queued so far: wait for the latest upload event unless this stream
+// already has.  (Per stream, not per scene: with frames on several streams each of them has to be ordered.)
+int Scene::frame_begin(hipStream_t stream) {
+	if (failed_) { set_error("a streaming batch failed on this scene: call bm_scene_reset_residency / bm_scene_preload_all"); return BM_ESTATE; }
+	FrameStream* fs = nullptr;
+	for (FrameStream& f : frame_streams_) if (f.stream == stream) { fs = &f; break; }
+	if (!fs) {
+		if (frame_streams_.size() >= kMaxFrameStreams) {
+			// retire the entry that has been idle longest (a caller that keeps creating streams): its last frame must have
+			// finished before the entry -- and with it the ordering of the load stream behind that frame -- can go
+			size_t lru = 0;
+			for (size_t i = 1; i < frame_streams_.size(); ++i) if (frame_streams_[i].last_use < frame_streams_[lru].last_use) lru = i;
+			BM_HIP(hipEventSynchronize(frame_streams_[lru].done));
+			BM_HIP(hipEventDestroy(frame_streams_[lru].done));
+			frame_streams_.erase(frame_streams_.begin() + static_cast<long>(lru));
+		}
+		FrameStream f;
+		f.stream = stream;
+		BM_HIP(hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+		frame_streams_.push_back(f);
+		fs = &frame_streams_.back();
+	}
+	if (fs->upload_seen < upload_seq_) {
+		BM_HIP(hipStreamWaitEvent(stream, ev_upload_, 0)); // ev_upload_ is re-recorded behind every batch: waiting for it covers all earlier ones
+		fs->upload_seen = upload_seq_;
+	}
+	fs->last_use = ++frame_seq_;
+	return 0;
+}
+
+int Scene::frame_end(hipStream_t stream) {
+	for (FrameStream& f : frame_streams_)
+		if (f.stream == stream) { BM_HIP(hipEventRecord(f.done, stream)); return 0; }
+	set_error("frame_end without frame_begin");
+	return BM_ESTATE;
+}
+
+int Scene::wait_frames_on_host() {
+	for (FrameStream& f : frame_streams_) BM_HIP(hipEventSynchronize(f.done));
+	return 0;
+}
+
+int Scene::order_load_stream_behind_frames() {
+	for (FrameStream& f : frame_streams_) BM_HIP(hipStreamWaitEvent(load_stream_, f.done, 0));
+	return 0;
+}
+
+void Scene::drop_frame_streams() {
+	for (FrameStream& f : frame_streams_) if (f.done) (void)hipEventDestroy(f.done);
+	frame_streams_.clear();
 }
 
 // ---------------------------------------------------------------- streaming
@@ -474,24 +667,36 @@ int Scene::preload_all() {
 int Scene::service_ring(int ring, uint32_t count) {
 	const WorldDims& d = world.dims;
 	const int* pos = h_positions_[ring];
-	if (upload_pending_) BM_HIP(hipEventSynchronize(ev_upload_)); // the staging buffers of the previous upload are free again
-	uint32_t n_moves = 0;
-	std::unordered_map<int, uint32_t> batch_first_resident, batch_move; // per supercell: bricks resident before this batch / its entry in h_moves_
+	// ---- pass 1: nothing is mutated before every entry has been checked (the positions come back from device memory:
+	// never index host arrays with an entry that cannot be a request)
 	for (uint32_t i = 0; i < count; ++i) {
 		const int px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
-		// the positions come back from device memory: never index host arrays with an entry that cannot be a request
 		if (px < 0 || py < 0 || pz < 0 || px >= d.cells || py >= d.cells || pz >= d.cells_height) {
 			set_error("brick request ring holds a position outside the world");
 			return BM_ESTATE;
 		}
-		const int sci = d.supercell_id(px / kSupercell, py / kSupercell, pz / kSupercell);
-		HostSupercell& c = world.supercells[sci];
-		const uint32_t local = static_cast<uint32_t>((px % kSupercell) + (py % kSupercell) * kSupercell + (pz % kSupercell) * kSupercell * kSupercell);
-		const uint32_t word = c.indices[local];
+		const HostSupercell& c = world.supercells[d.supercell_id(px / kSupercell, py / kSupercell, pz / kSupercell)];
+		const uint32_t word = c.indices[static_cast<uint32_t>((px % kSupercell) + (py % kSupercell) * kSupercell + (pz % kSupercell) * kSupercell * kSupercell)];
 		if (!(word & BM_BRICK_LOADED_BIT) || (word & BM_BRICK_INDEX_BITS) >= c.bricks.size()) {
 			set_error("brick request ring names an empty brick");
 			return BM_ESTATE;
 		}
+	}
+	if (staging_busy_) { // the staging buffers of the previous upload are free again once its copies have run
+		BM_HIP(hipEventSynchronize(ev_upload_));
+		staging_busy_ = false;
+	}
+	// ---- pass 2: hand out slots, grow pools.  From here on host state changes entry by entry; the only thing that can
+	// still go wrong is running out of device memory while the arena grows, and that leaves the scene marked as failed
+	// (every later frame / batch is refused until the residency is reset) instead of half-updated and in use.
+	uint32_t n_moves = 0;
+	std::unordered_map<int, uint32_t> batch_first_resident, batch_move; // per supercell: bricks resident before this batch / its entry in h_moves_
+	for (uint32_t i = 0; i < count; ++i) {
+		const int px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+		const int sci = d.supercell_id(px / kSupercell, py / kSupercell, pz / kSupercell);
+		HostSupercell& c = world.supercells[sci];
+		const uint32_t local = static_cast<uint32_t>((px % kSupercell) + (py % kSupercell) * kSupercell + (pz % kSupercell) * kSupercell * kSupercell);
+		const uint32_t word = c.indices[local];
 		std::memcpy(h_bricks_ + static_cast<size_t>(i) * kBrickWords, c.bricks[word & BM_BRICK_INDEX_BITS].data, sizeof(Brick));
 		// slots are handed out in request order (gpu_index_highest++, Scene.cpp:224); a full pool doubles first
 		// (Scene.cpp:231-251: 2^ceil(log2(highest + 1))) -- here it moves to a larger region of the arena
@@ -499,7 +704,7 @@ int Scene::service_ring(int ring, uint32_t count) {
 		if (c.resident >= c.pool_capacity) {
 			const uint32_t grown = std::max<uint32_t>(kStartingPool, c.pool_capacity * 2u);
 			uint32_t fresh = 0;
-			if (int e = region_alloc(grown, &fresh)) return e;
+			if (int e = region_alloc(grown, &fresh)) { failed_ = true; return e; }
 			// Only the bricks that were resident BEFORE this batch have to be copied (the batch's own bricks are scattered to
 			// base + slot after the bases are published), and only once: a pool that grows twice in one batch moves from
 			// the region it had when the batch began straight to the last one.
@@ -517,27 +722,33 @@ int Scene::service_ring(int ring, uint32_t count) {
 		h_indices_[i] = c.resident | BM_BRICK_LOADED_BIT | (word & BM_BRICK_LOD_BITS);
 		c.resident++;
 	}
-	BM_HIP(hipMemcpyAsync(d_bricks_queue_, h_bricks_, static_cast<size_t>(count) * sizeof(Brick), hipMemcpyHostToDevice, load_stream_));    // :228
-	BM_HIP(hipMemcpyAsync(d_indices_queue_, h_indices_, static_cast<size_t>(count) * sizeof(uint32_t), hipMemcpyHostToDevice, load_stream_)); // :229
-	// The scatter kernel rewrites index words that a frame still in flight may be reading and requesting through
-	// (plain load + atomicOr): a word flipping to "loaded" between the two would be requested a second time.  In
-	// overlapped mode it therefore runs behind that frame (ev_frame_done_); the copies above already overlap it.
-	if (overlapped_ && any_frame()) BM_HIP(hipStreamWaitEvent(load_stream_, ev_frame_done_, 0));
-	DeviceScene ring_view = view_;
-	ring_view.load_queue = d_load_queue_[ring];
-	ring_view.load_queue_count = d_load_count_[ring];
-	if (n_moves > 0) { // grown pools: copy their bricks to the new regions and publish the new bases, ahead of the scatter
-		BM_HIP(hipMemcpyAsync(d_moves_, h_moves_, static_cast<size_t>(n_moves) * sizeof(PoolMove), hipMemcpyHostToDevice, load_stream_));
-		launch_pool_moves(d_moves_, n_moves, d_arena_, d_pool_base_, load_stream_);
+	auto queue = [&]() -> int {
+		BM_HIP(hipMemcpyAsync(d_bricks_queue_, h_bricks_, static_cast<size_t>(count) * sizeof(Brick), hipMemcpyHostToDevice, load_stream_));    // :228
+		BM_HIP(hipMemcpyAsync(d_indices_queue_, h_indices_, static_cast<size_t>(count) * sizeof(uint32_t), hipMemcpyHostToDevice, load_stream_)); // :229
+		// The scatter kernel rewrites index words that a frame still in flight may be reading and requesting through
+		// (plain load + atomicOr): a word flipping to "loaded" between the two would be requested a second time; the move
+		// kernel rewrites pool bases such a frame addresses bricks with.  In overlapped mode both therefore run behind every
+		// frame in flight, whatever stream it is on; the copies above already overlap them.
+		if (overlapped_) { if (int e = order_load_stream_behind_frames()) return e; }
+		DeviceScene ring_view = view_;
+		ring_view.load_queue = d_load_queue_[ring];
+		ring_view.load_queue_count = d_load_count_[ring];
+		if (n_moves > 0) { // grown pools: copy their bricks to the new regions and publish the new bases, ahead of the scatter
+			BM_HIP(hipMemcpyAsync(d_moves_, h_moves_, static_cast<size_t>(n_moves) * sizeof(PoolMove), hipMemcpyHostToDevice, load_stream_));
+			launch_pool_moves(d_moves_, n_moves, d_arena_, d_pool_base_, load_stream_);
+			BM_HIP(hipGetLastError());
+		}
+		launch_upload(ring_view, d_bricks_queue_, d_indices_queue_, d_arena_, count, load_stream_); // kernel.cu:412
 		BM_HIP(hipGetLastError());
-	}
+		BM_HIP(hipMemsetAsync(d_load_count_[ring], 0, sizeof(uint32_t), load_stream_));             // kernel.cu:413
+		BM_HIP(hipEventRecord(ev_upload_, load_stream_));
+		return 0;
+	};
+	if (int e = queue()) { failed_ = true; return e; } // the host bookkeeping is ahead of the device: refuse to go on
 	for (const auto& f : freed_this_batch_) free_regions_[f.first].push_back(f.second); // reusable by the NEXT batch
 	freed_this_batch_.clear();
-	launch_upload(ring_view, d_bricks_queue_, d_indices_queue_, d_arena_, count, load_stream_); // kernel.cu:412
-	BM_HIP(hipGetLastError());
-	BM_HIP(hipMemsetAsync(d_load_count_[ring], 0, sizeof(uint32_t), load_stream_));             // kernel.cu:413
-	BM_HIP(hipEventRecord(ev_upload_, load_stream_));
-	upload_pending_ = true;
+	staging_busy_ = true;
+	upload_seq_++;
 	resident_bricks_ += count;
 	return 0;
 }
@@ -545,11 +756,12 @@ int Scene::service_ring(int ring, uint32_t count) {
 int Scene::process_load_queue(uint32_t* serviced) {
 	if (serviced) *serviced = 0;
 	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
+	if (failed_) { set_error("a streaming batch failed on this scene: call bm_scene_reset_residency / bm_scene_preload_all"); return BM_ESTATE; }
 	BM_HIP(hipSetDevice(device_));
 	if (!overlapped_) {
-		// ---- reference order (main.cpp:142-144): the frame that raised the requests has finished (kernel.cu:431), the host
+		// ---- reference order (main.cpp:142-144): the frames that raised the requests have finished (kernel.cu:431), the host
 		// reads the ring, stages, uploads; the next frame sees the bricks
-		if (any_frame()) BM_HIP(hipEventSynchronize(ev_frame_done_)); // recorded behind the last frame on whatever stream it ran
+		if (int e = wait_frames_on_host()) return e; // every stream a frame was issued on
 		BM_HIP(hipMemcpyAsync(h_count_[0], d_load_count_[0], sizeof(uint32_t), hipMemcpyDeviceToHost, load_stream_)); // Scene.cpp:202
 		BM_HIP(hipStreamSynchronize(load_stream_));
 		const uint32_t count = std::min<uint32_t>(static_cast<uint32_t>(queue_cap_), *h_count_[0]);                   // Scene.cpp:203
@@ -572,7 +784,7 @@ int Scene::process_load_queue(uint32_t* serviced) {
 			if (serviced) *serviced = count;
 		}
 	}
-	if (any_frame()) BM_HIP(hipStreamWaitEvent(load_stream_, ev_frame_done_, 0));
+	if (int e = order_load_stream_behind_frames()) return e; // the ring is complete once every frame that may append to it has ended
 	const int ring = ring_cur_;
 	BM_HIP(hipMemcpyAsync(h_count_[ring], d_load_count_[ring], sizeof(uint32_t), hipMemcpyDeviceToHost, load_stream_));
 	BM_HIP(hipMemcpyAsync(h_positions_[ring], d_load_queue_[ring], static_cast<size_t>(queue_cap_) * 3 * sizeof(int), hipMemcpyDeviceToHost, load_stream_));
@@ -608,6 +820,10 @@ int Scene::info(bm_scene_info* out) {
 	out->brick_bytes = on_device_ ? arena_capacity_ * 64 : 0;
 	out->pool_bytes = on_device_ ? pool_bricks_ * 64 : 0;
 	out->cube_field_bytes = on_device_ ? cube_field_bytes_ : 0;
+	out->arena_growths = arena_growths_;
+	out->arena_copy_growths = arena_copy_growths_;
+	out->arena_virtual = arena_virtual_ ? 1 : 0;
+	out->failed = failed_ ? 1 : 0;
 	return 0;
 }
 
@@ -641,11 +857,7 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 	BM_HIP(hipSetDevice(device_));
 	// `stream` is used as given: nullptr is HIP's default stream (what the reference's <<<>>> launches use), which is
 	// ordered with the caller's other default-stream work (e.g. torch's fill kernels on the accumulation buffer).
-	if (upload_pending_) { // bricks uploaded on the load stream must be visible to this frame
-		BM_HIP(hipStreamWaitEvent(stream, ev_upload_, 0));
-		upload_pending_ = false;
-	}
-	if (dbg && (fp->flags & BM_FLAG_SAMPLE_ITEMS)) { set_error("hit records are per pixel: not available with BM_FLAG_SAMPLE_ITEMS"); return BM_EINVAL; }
+	if (int e = frame_begin(stream)) return e; // bricks uploaded on the load stream must be visible to this frame
 	const bool instrumented = dbg != nullptr || (fp->flags & BM_FLAG_COUNTERS);
 	const int slot = static_cast<int>(launches_ % kTimingRing);
 	uint32_t* const work_counter = d_work_counter_ + static_cast<size_t>(slot) * (kWorkCounterBytes / sizeof(uint32_t)); // this launch's own block
@@ -666,7 +878,7 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 				 compute_units_ * blocks_per_cu_[instrumented ? 1 : 0], stream);
 	BM_HIP(hipGetLastError());
 	BM_HIP(hipEventRecord(ev_stop_[slot], stream));
-	BM_HIP(hipEventRecord(ev_frame_done_, stream)); // what process_load_queue waits for (the caller's stream may be gone by then)
+	if (int e = frame_end(stream)) return e; // what process_load_queue orders itself behind
 	launches_++;
 	return 0;
 }
@@ -674,10 +886,7 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 int Scene::begin_frame(hipStream_t stream, DeviceScene* view, DeviceCounters** counters) {
 	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
 	BM_HIP(hipSetDevice(device_));
-	if (upload_pending_) { // bricks uploaded on the load stream must be visible to this frame
-		BM_HIP(hipStreamWaitEvent(stream, ev_upload_, 0));
-		upload_pending_ = false;
-	}
+	if (int e = frame_begin(stream)) return e; // bricks uploaded on the load stream must be visible to this frame
 	if (view) *view = view_;
 	if (counters) *counters = d_counters_;
 	return 0;
@@ -685,7 +894,7 @@ int Scene::begin_frame(hipStream_t stream, DeviceScene* view, DeviceCounters** c
 
 void Scene::end_frame(hipStream_t stream) {
 	other_frames_++;
-	(void)hipEventRecord(ev_frame_done_, stream);
+	(void)frame_end(stream);
 }
 
 int Scene::resolve(const float* accum, float* out, long long n, hipStream_t stream) {

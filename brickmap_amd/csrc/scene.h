@@ -76,8 +76,27 @@ private:
 	hipEvent_t ev_upload_ = nullptr;
 	long long launches_ = 0;       // render() launches (index into the timing ring)
 	long long other_frames_ = 0;   // frames issued through begin_frame / end_frame
-	bool any_frame() const { return launches_ + other_frames_ > 0; }
-	bool upload_pending_ = false;
+	// Ordering between frames and brick uploads.  Frames may be issued on any number of streams (bench.py --pipeline, the
+	// multi-stream tests); uploads run on the load stream.  Every stream a frame was issued on has an entry here:
+	// `done` is recorded behind its most recent frame (process_load_queue orders the ring copy-out and the scatter kernel
+	// behind ALL of them, not only behind the last frame launched), `upload_seen` is the upload batch the stream has
+	// already been ordered behind (a frame waits for ev_upload_ when its stream has not seen the latest batch).
+	struct FrameStream {
+		hipStream_t stream = nullptr;
+		hipEvent_t done = nullptr;
+		uint64_t upload_seen = 0;
+		uint64_t last_use = 0;
+	};
+	static constexpr size_t kMaxFrameStreams = 16;
+	std::vector<FrameStream> frame_streams_;
+	uint64_t upload_seq_ = 0, frame_seq_ = 0; // upload batches queued on the load stream / frames issued
+	bool staging_busy_ = false;               // the pinned staging buffers belong to an upload that may still be copying
+	bool failed_ = false;                     // a streaming batch could not be completed (allocation failure): residency state is undefined until reset
+	int frame_begin(hipStream_t stream);      // order `stream` behind pending uploads
+	int frame_end(hipStream_t stream);        // record the stream's "frame done" event
+	int wait_frames_on_host();                // host waits for every frame in flight
+	int order_load_stream_behind_frames();    // load stream waits for every frame in flight
+	void drop_frame_streams();
 
 	// device memory (DeviceScene view)
 	uint32_t* d_index_grid_ = nullptr;
@@ -103,11 +122,22 @@ private:
 	uint32_t* h_count_[2] = {nullptr, nullptr};
 	bool overlapped_ = false, snapshot_pending_ = false;
 	int ring_cur_ = 0, ring_snapshot_ = 0;
-	hipEvent_t ev_snapshot_ = nullptr, ev_frame_done_ = nullptr;
+	hipEvent_t ev_snapshot_ = nullptr;
 
-	// ---- brick arena: one device allocation that every supercell's pool lives in (Scene.cpp:152-175,231-251 made one
+	// ---- brick arena: one device address range that every supercell's pool lives in (Scene.cpp:152-175,231-251 made one
 	// allocator).  Regions are powers of two of at least kStartingPool bricks, handed out from per-size free lists or
-	// from the top of the arena; the arena itself doubles when it is full (a rare, synchronising reallocation).
+	// from the top of the arena.  The arena is a RESERVED VIRTUAL RANGE sized for the world's worst case into which
+	// physical chunks are mapped as residency grows (hipMemAddressReserve / hipMemCreate / hipMemMap): growing it
+	// neither copies a brick nor synchronises the device, and every pointer into it stays valid for frames in flight.
+	// (Devices without virtual memory management fall back to reallocate + copy behind a device synchronisation.)
+	bool arena_virtual_ = false;
+	size_t arena_va_bytes_ = 0, arena_granularity_ = 0;
+	struct ArenaChunk { hipMemGenericAllocationHandle_t handle; size_t offset, bytes; };
+	std::vector<ArenaChunk> arena_chunks_;
+	uint64_t arena_growths_ = 0, arena_copy_growths_ = 0; // times the arena grew / grew by synchronise + copy
+	int arena_open(uint64_t max_bricks);  // reserve the address range (once per world)
+	int arena_unmap_all();
+	void arena_close();
 	static constexpr uint32_t kStartingPool = 16; // supergrid_starting_size, variables.h:15
 	uint64_t arena_capacity_ = 0, arena_top_ = 0; // bricks
 	uint64_t pool_bricks_ = 0;                    // bricks of capacity currently handed to pools

@@ -349,8 +349,17 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						}
 						if (DBG && dbg) {
 							uint32_t* d = dbg + static_cast<size_t>(local_pixel) * 8;
-							d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = hseg; d[5] = hsh; d[6] = next | (nsh << 16);
-							d[7] = tally.index_loads - loads0;
+							if (sample_items) {
+								// one item = one sample: the pixel's record becomes an order-independent digest -- the SUMS (mod 2^32) of
+								// the per-sample path hashes, ray counts and cell counts (the caller zeroes the buffer); the first-hit
+								// record is that of sample 0, written by the one item that traced it
+								if (s_end == 1) { d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; }
+								atomicAdd(d + 4, hseg); atomicAdd(d + 5, hsh); atomicAdd(d + 6, next | (nsh << 16));
+								atomicAdd(d + 7, tally.index_loads - loads0);
+							} else {
+								d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = hseg; d[5] = hsh; d[6] = next | (nsh << 16);
+								d[7] = tally.index_loads - loads0;
+							}
 						}
 						state = ST_IDLE;
 					} else {

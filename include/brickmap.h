@@ -39,7 +39,10 @@ extern "C" {
 #define BM_FLAG_PRIMARY_ONLY 1u /* BASELINE config 1: extend the primary ray only          */
 #define BM_FLAG_COUNTERS 2u     /* accumulate the traversal counters (instrumented kernel)  */
 #define BM_FLAG_SAMPLE_ITEMS 4u /* schedule (4x4 chunk, sample) work items instead of pixels: samples of a pixel run on
-                                   different lanes and are summed with float atomics (order not fixed; no debug_dev).
+                                   different lanes and are summed with float atomics (order not fixed).  debug_dev then
+                                   holds an order-independent digest per pixel: words 4-7 are the SUMS (mod 2^32) over the
+                                   samples of the per-sample path hashes / ray counts / cell counts (zero the buffer first),
+                                   words 0-3 the first-hit record of the launch's first sample.
                                    For shards with few pixels and many samples, e.g. 1/N row bands of a multi-GPU frame */
 
 typedef struct bm_scene bm_scene; /* Scene + its GPUScene view (Scene.h:7-44), one GPU */
@@ -84,6 +87,11 @@ typedef struct bm_scene_info {
 	uint64_t index_bytes, brick_bytes; /* device allocations: index grid; brick arena as allocated (grows by residency) */
 	uint64_t pool_bytes;            /* part of the arena handed to supercell pools (16-brick pools that double, Scene.cpp:231-251) */
 	uint64_t cube_field_bytes;      /* octant cube field of the walk (8 bytes per brick cell) */
+	uint64_t arena_growths;         /* times the brick arena grew while bricks were resident (pool growth, Scene.cpp:231-251)      */
+	uint64_t arena_copy_growths;    /* ... of which by device synchronisation + reallocation + copy: 0 when the arena is a virtual
+	                                   address range that physical chunks are mapped into (arena_virtual)                        */
+	int32_t arena_virtual;          /* 1: hipMemAddressReserve / hipMemMap arena (grows without copy or synchronisation)          */
+	int32_t failed;                 /* 1: a streaming batch could not be completed; frames are refused until the residency is reset */
 } bm_scene_info;
 
 /* traversal counters (BM_FLAG_COUNTERS); same order as oracle/oracle.c orc_counters */
@@ -126,7 +134,9 @@ BM_API int bm_scene_set_streaming_mode(bm_scene* scene, int overlapped);
 /* Scene::generate (Scene.cpp:118-194): CPU world build on `threads` host threads, then the
  * device allocations in the reference's initial state (nothing resident: unloaded|lod). */
 BM_API int bm_scene_generate(bm_scene* scene, int threads);
-/* Scene::generate_supercell (Scene.cpp:44-116): rebuild one supercell on the host (does not touch the device). */
+/* Scene::generate_supercell (Scene.cpp:44-116): rebuild one supercell on the host.  Only before bm_scene_generate has put
+ * the world on the device (BM_ESTATE afterwards: the pools hold bricks in request order and the index words name those
+ * slots; the reference never regenerates a supercell of a live scene either). */
 BM_API int bm_scene_generate_supercell(bm_scene* scene, int sx, int sy, int sz);
 /* BASELINE configs 1-2 "all bricks pre-loaded": device words = host words, arena = every host brick. */
 BM_API int bm_scene_preload_all(bm_scene* scene);
@@ -183,8 +193,10 @@ BM_API int bm_local_rows(const bm_frame_params* params);
  * Frames of one scene that accumulate into the SAME buffer may overlap in time (issued on different streams) only
  * with BM_FLAG_SAMPLE_ITEMS, which adds samples with float atomics; without it a pixel is read when a lane takes it
  * and written back when it is done, so such frames must be ordered (one stream, or events).  Every launch has its
- * own ticket counters and constants (a ring of 256 launches in flight).  Scenes that stream bricks order uploads
- * against ONE stream: keep their frames on one stream.  Width and height are limited to 65535, a shard to 2^32 pixels. */
+ * own ticket counters and constants (a ring of 256 launches in flight).  Scenes that stream bricks may have frames on
+ * several streams as well: every stream is ordered behind the brick uploads it has not seen, and
+ * bm_scene_process_load_queue orders itself behind the frames of all of them.  Width and height are limited to 65535, a
+ * shard to 2^32 pixels. */
 BM_API int bm_render_frame(bm_scene* scene, const bm_camera* camera, const bm_frame_params* params,
                            float* accum_dev, uint32_t* debug_dev, void* hip_stream);
 /* blit_onto_framebuffer (kernel.cu:348-364) into an offscreen float4 buffer: rgb/a, a=1, gamma 1/2.2 */

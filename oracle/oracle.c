@@ -1187,6 +1187,7 @@ ORC_API void orc_wavefront_stats(const orc_wavefront* s, unsigned* out6) {
 ORC_API int orc_wavefront_read_queue(const orc_wavefront* s, int which, unsigned first, unsigned count, void* out) {
 	if (first > s->queue_size || count > s->queue_size - first) return -1;
 	if (which == 0) memcpy(out, s->work + first, (size_t)count * sizeof(RayQueue));
+	else if (which == 2) memcpy(out, s->next + first, (size_t)count * sizeof(RayQueue)); /* the rays extend traced in the last frame (queue before the swap) */
 	else memcpy(out, s->shadow + first, (size_t)count * sizeof(ShadowQueue));
 	return 0;
 }

@@ -33,7 +33,7 @@ static uint32_t bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
 int main(int argc, char** argv) {
 	const long rays = argc > 1 ? std::atol(argv[1]) : 200000;
-	long jumps = 0, exits = 0, steps_total = 0, skipped_pre = 0, failures = 0;
+	long jumps = 0, exits = 0, steps_total = 0, skipped_pre = 0, failures = 0, multi = 0, multi_iters = 0;
 	long len_hist[10] = {0};
 	for (long ray = 0; ray < rays; ++ray) {
 		// direction: mostly random unit vectors, some near-axis / near-diagonal / power-of-two-slope ones (ties)
@@ -97,6 +97,33 @@ int main(int argc, char** argv) {
 										 r.t[0], r.t[1], r.t[2]);
 						failures++;
 					}
+					// ---- a jump that stopped at a binade end may go on with what is left of the budget on every axis (dda_jump3,
+					// traverse.h field_jump with BM_JUMP_BINADES > 1): up to three more binades, then the same comparison
+					if (ok && !exited && rnd() % 2 == 0) {
+						uint32_t b[3] = {n - c[0], n - c[1], n - c[2]}, tc[3] = {c[0], c[1], c[2]};
+						bool ex2 = false;
+						int last2 = -1;
+						for (int it = 0; it < 3 && !ex2 && bm::jump_possible(jt[0], jt[1], jt[2]); ++it) {
+							uint32_t a[3];
+							ex2 = bm::dda_jump3(jt[0], jt[1], jt[2], s.d[0], s.d[1], s.d[2], inv[0], inv[1], inv[2], b[0], b[1], b[2], a[0], a[1], a[2], last2);
+							for (int i = 0; i < 3; ++i) { tc[i] += a[i]; ok = ok && a[i] <= b[i]; b[i] -= a[i]; }
+							multi_iters++;
+						}
+						Dda r2 = s;
+						uint32_t rc2[3] = {0, 0, 0};
+						int rlast2 = -1;
+						const uint32_t total2 = tc[0] + tc[1] + tc[2];
+						for (uint32_t q = 0; ok && q < total2; ++q) { rlast2 = r2.step(); rc2[rlast2]++; }
+						int at_n2 = 0;
+						for (int i = 0; i < 3; ++i) { ok = ok && rc2[i] == tc[i] && bits(r2.t[i]) == bits(jt[i]) && tc[i] <= n; at_n2 += tc[i] == n; }
+						if (ex2) ok = ok && rlast2 == last2;
+						ok = ok && (at_n2 == 0 || (ex2 && at_n2 == 1 && tc[last2] == n)); // never past the cube
+						if (!ok) {
+							if (failures < 10) std::fprintf(stderr, "MISMATCH (continued jump) ray %ld n %u c=(%u %u %u) replay=(%u %u %u)\n", ray, n, tc[0], tc[1], tc[2], rc2[0], rc2[1], rc2[2]);
+							failures++;
+						}
+						multi++;
+					}
 					jumps++;
 					exits += exited;
 					steps_total += total;
@@ -110,6 +137,7 @@ int main(int argc, char** argv) {
 	}
 	std::printf("jumps %ld exits %ld steps %ld (%.1f per jump) precondition-skips %ld failures %ld\n", jumps, exits, steps_total, jumps ? double(steps_total) / jumps : 0.0,
 				skipped_pre, failures);
+	std::printf("continued jumps %ld (%ld further binades)\n", multi, multi_iters);
 	std::printf("jump length histogram (<=1,2,4,...):");
 	for (int i = 0; i < 10; ++i) std::printf(" %ld", len_hist[i]);
 	std::printf("\n");

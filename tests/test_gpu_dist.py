@@ -1,0 +1,47 @@
+"""The RCCL ("nccl" backend) side of the multi-GPU path, as far as ONE GPU can take it: a world-size-1 process group on the
+GPU box pushes frames through FrameGatherer / FrameReducer on device tensors, and bench.py runs its whole multi-GPU code
+path (BM_BENCH_FORCE_DIST=1) with a single rank.  What stays unexercised without a second GPU is only the peer-to-peer
+transport itself; world sizes 2 and 3 are covered on CPU with gloo (tests/test_dist_gloo.py) and with two processes on
+one GPU (tests/test_gpu_parity.py::test_bench_multi_rank_path_on_one_gpu)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_nccl_process_group_with_one_rank_moves_frames():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_worker.py"), str(free_port())], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "NCCL_DRY_RUN_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("extra", [[], ["--pipeline", "2"], ["--decomposition", "samples"]])
+def test_bench_multi_gpu_code_path_on_nccl_with_one_rank(extra):
+    """bench.py's N > 1 path (RCCL process group, row-band shard with (chunk, sample) items, pipelined device gather,
+    barrier, max-over-ranks all_reduce, --verify, same_job_single_gpu) with WORLD_SIZE = 1."""
+    env = dict(os.environ, BM_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--workload", "config1", "--verify"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-1500:]
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "strong" and out["config"]["spp_per_step"] == 8
+    assert out["verified_against_single_gpu"]["frames"] == 5 and out["verified_against_single_gpu"]["max_rel_err"] < 1e-5
+    assert out["same_job_single_gpu"]["ms_per_step"] > 0 and "cpu_baseline" not in out

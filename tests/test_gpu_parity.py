@@ -535,13 +535,20 @@ def full_size_sharded_job(bm, orc, torch, scene, cam, ocam, oracle_world, W, H, 
     dbg = torch.zeros((H, W, 8), dtype=torch.int32, device="cuda:0")
     scene.render(cam, whole, torch.zeros_like(full), debug=dbg)  # hit records of the same frame (instrumented instantiation)
     assembled = torch.zeros_like(full)
+    digest = torch.zeros_like(dbg)
     for r in range(shards):
         p = bm.FrameParams(W, H, spp=spp, max_bounces=7, band_rows=band, shard_rank=r, shard_count=shards, flags=bm.BM_FLAG_SAMPLE_ITEMS)
         packed = torch.zeros((bm.local_rows(p), W, 4), dtype=torch.float32, device="cuda:0")
         scene.render(cam, p, packed)
         rows = torch.as_tensor(bm.dist.shard_rows(H, band, r, shards), device="cuda:0", dtype=torch.long)
         assembled.index_copy_(0, rows, packed)
+        # the same shard once more with the instrumented instantiation: per-pixel digest of the (chunk, sample) items
+        packed_dbg = torch.zeros((bm.local_rows(p), W, 8), dtype=torch.int32, device="cuda:0")
+        scene.render(cam, p, torch.zeros_like(packed), debug=packed_dbg)
+        digest.index_copy_(0, rows, packed_dbg)
     torch.cuda.synchronize()
+    # ray counts and cells visited per pixel are sums in both modes: the shards' items traced exactly the rays of the whole frame
+    assert torch.equal(digest[..., 6:], dbg[..., 6:]) and torch.equal(digest[..., :4], dbg[..., :4])
     if streamed:
         assert scene.process_load_queue() == 0  # the shards asked for nothing the whole frame had not
     a, f = assembled.cpu().numpy(), full.cpu().numpy()
@@ -554,6 +561,10 @@ def full_size_sharded_job(bm, orc, torch, scene, cam, ocam, oracle_world, W, H, 
     assert np.array_equal(dbg[rows_dev].cpu().numpy().view(np.uint32), odbg[rows])
     assert_radiance(f[rows], oacc[rows])
     assert_radiance(a[rows], oacc[rows])
+    # ... and the per-sample path hashes of the shards' work items sum to the oracle's on those rows: the mode the
+    # multi-GPU job runs in is pinned on hits, bit for bit, at full size
+    want = oracle_sample_digest(orc, oracle_world, ocam, W, H, spp, max_bounces=7, band_rows=1, shard_rank=oracle_row_groups // 3, shard_count=oracle_row_groups)
+    assert np.array_equal(digest[rows_dev].cpu().numpy().view(np.uint32), want[rows])
 
 
 def test_config5_like_lod_world_at_scale(bm, orc, torch_cuda):
@@ -629,6 +640,110 @@ def test_pool_growth_keeps_bricks_intact(bm, orc, torch_cuda):
         assert sorted(slots.tolist()) == list(range(len(loaded)))  # request order: dense, each slot once
         for local in loaded[:: max(1, len(loaded) // 60)]:
             assert np.array_equal(scene.device_brick(sc, int(dev[local] & 0xFFF)), host_bricks[host_idx[local] & 0xFFF])
+    scene.close()
+
+
+def test_generate_supercell_is_refused_on_a_live_scene(bm, orc, torch_cuda):
+    """Scene::generate_supercell rebuilds a HOST supercell and resets its slot counter; once pools hold bricks in request
+    order that would hand out slots twice, so the call is refused after generate() (and the stream goes on unharmed)."""
+    G = 256
+    scene = bm.Scene(G, G, device=0)
+    scene.generate_supercell(0, 0, 0)  # before generate(): allowed (host only, the reference's use)
+    scene.set_queue_capacity(128)
+    scene.generate()
+    cam, ocam = cameras(bm, orc, G)
+    p = bm.FrameParams(96, 64, spp=1, max_bounces=3)
+    for _ in range(3):
+        gpu_render(bm, torch_cuda, scene, cam, p, want_dbg=False)
+        scene.process_load_queue()
+    with pytest.raises(bm.BrickmapError):
+        scene.generate_supercell(0, 0, 0)
+    for _ in range(400):
+        gpu_render(bm, torch_cuda, scene, cam, p, want_dbg=False)
+        if scene.process_load_queue() == 0:
+            break
+    else:
+        pytest.fail("no streaming steady state")
+    acc, dbg = gpu_render(bm, torch_cuda, scene, cam, p)
+    w = orc.World(G, G)
+    w.reset_device(True)
+    oacc, odbg, _, _ = w.render(ocam, orc.make_frame(96, 64, spp=1, max_bounces=3))
+    assert np.array_equal(dbg, odbg)
+    assert_radiance(acc, oacc)
+    scene.close()
+
+
+def test_streaming_scene_with_frames_on_several_streams(bm, orc, torch_cuda):
+    """Frames of a STREAMING scene issued round-robin on three streams, both servicing modes: every stream is ordered behind
+    the uploads it has not seen and process_load_queue behind the frames of all of them, so the scene streams in as it does
+    on one stream -- every brick uploaded exactly once, nothing left half-requested, steady state == resident image."""
+    torch = torch_cuda
+    G, W, H = 256, 160, 120
+    cam, _ = cameras(bm, orc, G)
+    resident = bm.Scene(G, G, device=0).generate().preload_all()
+    want_acc, want_dbg = gpu_render(bm, torch, resident, cam, bm.FrameParams(W, H, spp=1, sample_base=0, max_bounces=3))
+    resident.close()
+    for overlapped in (False, True):
+        scene = bm.Scene(G, G, device=0)
+        scene.set_queue_capacity(512)
+        scene.generate()
+        scene.set_streaming_mode(overlapped)
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0") for _ in range(3)]
+        torch.cuda.synchronize()
+        total, idle = 0, 0
+        for k in range(1200):
+            j = k % 3
+            scene.render(cam, bm.FrameParams(W, H, spp=1, sample_base=k, max_bounces=3), bufs[j], stream=streams[j].cuda_stream)
+            n = scene.process_load_queue()
+            total += n
+            idle = idle + 1 if n == 0 else 0
+            if idle >= 6:
+                break
+        assert idle >= 6
+        torch.cuda.synchronize()
+        info = scene.info()
+        assert total == info["resident_bricks"] and info["failed"] == 0
+        nsc = info["supercells"]
+        loaded = sum(int(np.count_nonzero(scene.device_indices(sc) & bm.BRICK_LOADED_BIT)) for sc in range(nsc))
+        requested = sum(int(np.count_nonzero(scene.device_indices(sc) & bm.BRICK_REQUESTED_BIT)) for sc in range(nsc))
+        assert loaded == total and requested == 0
+        acc, dbg = gpu_render(bm, torch, scene, cam, bm.FrameParams(W, H, spp=1, sample_base=0, max_bounces=3))
+        assert np.array_equal(dbg, want_dbg) and np.array_equal(acc, want_acc)
+        scene.close()
+
+
+def test_arena_grows_without_stopping_the_world(bm, orc, torch_cuda):
+    """The brick arena is a reserved address range that physical chunks are mapped into: the config-5 world streams in from
+    nothing in overlapped mode with frames in flight, the arena grows several times, and none of the growths copies the
+    arena or synchronises the device (arena_copy_growths == 0); the steady-state image is the oracle's on sampled rows."""
+    G, W, H = 2048, 1024, 576
+    scene = bm.Scene(G, G, device=0)
+    scene.set_queue_capacity(1 << 18)
+    scene.generate()
+    scene.set_streaming_mode(True)
+    info0 = scene.info()
+    assert info0["arena_virtual"] == 1, "this device supports hipMemAddressReserve/hipMemMap: the arena must use it"
+    cam, ocam = cameras(bm, orc, G)
+    acc = torch_cuda.zeros((H, W, 4), dtype=torch_cuda.float32, device="cuda:0")
+    idle = 0
+    for k in range(400):
+        scene.render(cam, bm.FrameParams(W, H, spp=2, max_bounces=7), acc)  # the same paths every frame: the request set converges
+        idle = idle + 1 if scene.process_load_queue() == 0 else 0
+        if idle >= 3:
+            break
+    assert idle >= 3
+    info = scene.info()
+    assert info["arena_growths"] >= 2 and info["arena_copy_growths"] == 0 and info["failed"] == 0
+    assert info["brick_bytes"] > info0["brick_bytes"] and 64 * info["resident_bricks"] <= info["pool_bytes"] <= info["brick_bytes"]
+    p = bm.FrameParams(W, H, spp=1, max_bounces=7)
+    got, dbg = gpu_render(bm, torch_cuda, scene, cam, p)
+    w = orc.World(G, G, threads=os.cpu_count() or 1)
+    w.reset_device(True)
+    oacc, odbg, _, _ = w.render(ocam, orc.make_frame(W, H, spp=1, max_bounces=7, band_rows=1, shard_rank=7, shard_count=48), threads=os.cpu_count() or 1)
+    rows = bm.dist.shard_rows(H, 1, 7, 48)
+    assert np.array_equal(dbg[rows], odbg[rows])
+    assert_radiance(got[rows], oacc[rows])
     scene.close()
 
 
@@ -743,9 +858,50 @@ def test_sample_items_mode_matches_pixel_items(bm, orc, torch_cuda, scene256):
     got, _ = gpu_render(bm, torch_cuda, scene256, cam, bm.FrameParams(150, 90, spp=2, flags=bm.BM_FLAG_SAMPLE_ITEMS), accum=acc, want_dbg=False)
     want, _ = gpu_render(bm, torch_cuda, scene256, cam, bm.FrameParams(150, 90, spp=2), accum=torch_cuda.full((90, 150, 4), 2.0, dtype=torch_cuda.float32, device="cuda:0"), want_dbg=False)
     np.testing.assert_allclose(got, want, rtol=2e-6)
-    # hit records are per pixel: refused in this mode
-    with pytest.raises(bm.BrickmapError):
-        gpu_render(bm, torch_cuda, scene256, cam, bm.FrameParams(32, 32, spp=2, flags=bm.BM_FLAG_SAMPLE_ITEMS), want_dbg=True, also_plain=False)
+
+
+def oracle_sample_digest(orc, world, ocam, W, H, spp, sample_base=0, max_bounces=3, **shard):
+    """What debug_dev holds under BM_FLAG_SAMPLE_ITEMS, from the oracle: words 0-3 the first-hit record of the first sample,
+    words 4-7 the sums (mod 2^32) over the samples of the per-sample path hashes / ray counts / cell counts -- every sample
+    rendered on its own, so each hash chain covers exactly one path."""
+    total = None
+    for k in range(spp):
+        _, d, _, _ = world.render(ocam, orc.make_frame(W, H, spp=1, sample_base=sample_base + k, max_bounces=max_bounces, **shard), threads=os.cpu_count() or 1)
+        d = d.astype(np.uint32)
+        if total is None:
+            total = d.copy()
+        else:
+            total[..., 4:] += d[..., 4:]
+    return total
+
+
+def test_sample_items_digest_matches_oracle(bm, orc, torch_cuda, scene256, world256):
+    """The work-item mode every multi-GPU shard uses, pinned on GEOMETRY: per pixel the sum over its samples of the per-path
+    hit hashes (distance bits, normal, level, brick id, voxel id of every segment; occlusion + occluder of every shadow ray),
+    of the ray counts and of the cells visited equals the oracle's, bit for bit; radiance within 1e-4."""
+    torch = torch_cuda
+    world256.reset_device(True)
+    for (W, H, kw) in ((150, 90, dict(spp=5, sample_base=3)), (96, 64, dict(spp=3, band_rows=16, shard_rank=1, shard_count=2)), (64, 48, dict(spp=1))):
+        for pos, h, v in (((128, 32, 204.8), 0.8, -0.5), ((40.5, 200.25, 150.0), 2.3, -0.2)):
+            cam, ocam = cameras(bm, orc, 256, pos=pos, h=h, v=v)
+            p = bm.FrameParams(W, H, max_bounces=3, flags=bm.BM_FLAG_SAMPLE_ITEMS, **kw)
+            rows = bm.local_rows(p)
+            acc = torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda:0")
+            dbg = torch.zeros((rows, W, 8), dtype=torch.int32, device="cuda:0")
+            scene256.render(cam, p, acc, debug=dbg)
+            plain = torch.zeros_like(acc)
+            scene256.render(cam, p, plain)  # the production instantiation in the same mode
+            torch.cuda.synchronize()
+            shard = {k: kw[k] for k in ("band_rows", "shard_rank", "shard_count") if k in kw}
+            want = oracle_sample_digest(orc, world256, ocam, W, H, kw["spp"], kw.get("sample_base", 0), **shard)
+            mine = bm.dist.shard_rows(H, kw.get("band_rows", H), kw.get("shard_rank", 0), kw.get("shard_count", 1))
+            got = dbg.cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, want[mine]), "sample-item digest differs from the oracle"
+            oacc, _, _, _ = world256.render(ocam, orc.make_frame(W, H, max_bounces=3, **kw), threads=os.cpu_count() or 1)
+            a, b = acc.cpu().numpy(), plain.cpu().numpy()
+            assert np.array_equal(a[..., 3], b[..., 3]) and np.array_equal(a[..., 3], oacc[mine][..., 3])
+            assert_radiance(a, oacc[mine])
+            assert_radiance(b, oacc[mine])
 
 
 def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
