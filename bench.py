@@ -41,7 +41,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r02"  # profiles/<round>_pmc_summary*.json is where roofline.traffic comes from
+# what bounds trace_paths on each workload (profiles/r03_pmc_summary_<workload>.json, profiles/r03_fetch_calibration.txt)
+LIMITER = {
+    "config1": "launch latency (a 256x256 frame is 65 k paths: less than one wave-load per SIMD)",
+    "config2": "VALU issue: the vector pipes are busy for the whole launch with ~20 of 64 lanes active per instruction; the scene (93 MiB) stays in L2 / Infinity Cache",
+    "config3": "VALU issue, with 0.6 G L2 sector misses per launch (TCC hit 61 %)",
+    "config4": "VALU issue, with 0.6 G L2 sector misses per launch (TCC hit 61 %)",
+    "config5": "fabric request rate: 41.5 G single-sector (64 B) read requests/s, 85 % of the 48 G/s this GPU sustains for random sectors (= 3.1 TB/s, not the 8 TB/s byte peak)",
+}
+PROFILE_ROUND = "r03"  # profiles/<round>_pmc_summary*.json is where roofline.traffic comes from
 
 
 def workload(name):
@@ -396,6 +404,12 @@ def main():
                  "actual_Mrays_s_rank0_kernel": round(actual_rays / args.steps / avg_kernel_s / 1e6, 2)},
         "roofline": {
             "bound": "hbm",
+            # what `achieved` is: SURVEY.md 8(d)'s ALGORITHMIC bytes -- the traffic of the REFERENCE's walk over the same rays
+            # (4 B per cell it would load + 64 B per brick test + 16 B per pixel) -- divided by this kernel's duration.  The
+            # kernel itself reads far less (one cube-field byte per STOP of the walk, index words only at candidates: see
+            # `traffic`, from the PMC counters); `limiter` names what actually bounds it on this workload.
+            "achieved_is": "reference-equivalent (algorithmic) bytes per launch / kernel duration",
+            "limiter": LIMITER.get(args.workload, LIMITER["config2"]),
             "achieved": round(achieved_gbs, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -580,11 +594,12 @@ def cpu_baseline(W, H, max_bounces, G, cam):
 
 
 def pmc_traffic(workload):
-    """{"traffic": HBM bytes per launch, "traffic_source": where it comes from}.  The counters are NOT collected by this
-    run (rocprofv3 PMC needs its own passes, tools/pmc.sh): the figure is read from the committed summary of the same
-    workload and kernel, and the source is named in the line.  Units and correction as MI355X_MICROARCH.md (HBM section)
-    prescribes: FETCH_SIZE and WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, i.e.
-    reports half of a 16 B/lane stream, so it is doubled; WRITE_SIZE is taken as reported (uncalibrated per the guide)."""
+    """{"traffic": fabric-side bytes per launch, "traffic_source": where it comes from}.  The counters are NOT collected by
+    this run (rocprofv3 PMC needs its own passes, tools/profile_workload.py): the figure is read from the committed summary of
+    the same workload and kernel, and the source is named in the line.  FETCH_SIZE and WRITE_SIZE are KiB.  On gfx950
+    FETCH_SIZE = read requests x 64 B: the guide's x2 applies to full-line coalesced streams only; every read of this
+    kernel is a single 64-byte sector request, for which FETCH_SIZE is exact (profiles/r03_fetch_calibration.txt, measured
+    with tools/ubench/fetch_calib.hip on 1-byte / 4-byte / 64-byte gathers) -- factor 1.0.  Infinity-Cache hits are included."""
     name = f"pmc_summary_{workload}.json"
     path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_" + name)
     try:
@@ -592,7 +607,7 @@ def pmc_traffic(workload):
             d = json.load(f)
         if d.get("workload") != workload:
             return {"traffic": None, "traffic_source": None}
-        return {"traffic": int((2.0 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024),
+        return {"traffic": int((1.0 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024),
                 "traffic_source": f"profiles/{os.path.basename(path)} (separate rocprofv3 --pmc passes of this workload, not this run)"}
     except (OSError, KeyError, ValueError):
         return {"traffic": None, "traffic_source": None}

@@ -45,7 +45,8 @@ class bm_scene_info(C.Structure):
                 ("total_bricks", C.c_uint64), ("resident_bricks", C.c_uint64),
                 ("index_bytes", C.c_uint64), ("brick_bytes", C.c_uint64),
                 ("pool_bytes", C.c_uint64), ("cube_field_bytes", C.c_uint64),
-                ("arena_growths", C.c_uint64), ("arena_copy_growths", C.c_uint64), ("arena_virtual", C.c_int32), ("failed", C.c_int32)]
+                ("arena_growths", C.c_uint64), ("arena_copy_growths", C.c_uint64), ("arena_virtual", C.c_int32), ("failed", C.c_int32),
+                ("stream_batches", C.c_uint64), ("stream_host_ns", C.c_uint64)]
 
 
 COUNTER_NAMES = ("index_loads", "brick_tests", "byte_tests", "voxel_steps", "extend_rays",
@@ -106,6 +107,7 @@ SIGNATURES = {
     "bm_counters_read": (_i, [_vp, C.POINTER(bm_counters)]),
     "bm_counters_reset": (_i, [_vp]),
     "bm_sched_stats_read": (_i, [_vp, C.POINTER(bm_sched_stats)]),
+    "bm_sched_detail_read": (_i, [_vp, _vp]),
     "bm_wavefront_create": (_i, [_vp, C.c_uint32, C.POINTER(_vp)]),
     "bm_wavefront_destroy": (None, [_vp]),
     "bm_wavefront_reset": (_i, [_vp]),

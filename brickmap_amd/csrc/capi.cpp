@@ -197,6 +197,7 @@ int bm_render_times(bm_scene* scene, float* ms, int capacity, int* count) { BM_N
 int bm_counters_read(bm_scene* scene, bm_counters* out) { BM_NEED(scene); return scene->impl.counters_read(out); }
 int bm_counters_reset(bm_scene* scene) { BM_NEED(scene); return scene->impl.counters_reset(); }
 int bm_sched_stats_read(bm_scene* scene, bm_sched_stats* out) { BM_NEED(scene); return scene->impl.sched_stats_read(out); }
+int bm_sched_detail_read(bm_scene* scene, uint64_t* out8) { BM_NEED(scene); return scene->impl.sched_detail_read(out8); }
 
 int bm_wavefront_create(bm_scene* scene, uint32_t queue_size, bm_wavefront** out) {
 	BM_NEED(scene);

@@ -77,6 +77,10 @@ struct DeviceCounters { // v: same order as bm_counters; sched: same order as bm
 	unsigned long long v[8];
 	unsigned long long sched[8];
 	unsigned long long cycles[8]; // s_memtime ticks per scheduler phase, summed over waves: A, B, C, D, total; jump runs, jump lanes; waves
+	// -DBM_PHASE_TIMING builds only (bm_sched_detail_read): where a shade pass spends its time -- connect, shade (hit branch),
+	// sky model, pixel hand-back + primary ray, ray set-up -- then the number of candidate passes that walked a brick and the
+	// sum of their loop lengths (the longest 8^3 walk among the pass's lanes), and the sum of the lanes' own walk lengths
+	unsigned long long detail[8];
 };
 
 // ---- wavefront mode (wavefront.hip): the reference's queue records and device globals

@@ -2,6 +2,7 @@
 #include "scene.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -564,6 +565,7 @@ int Scene::reset_residency() {
 	resident_bricks_ = 0;
 	staging_busy_ = false;
 	failed_ = false;
+	stream_batches_ = stream_host_ns_ = 0;
 	upload_seq_ = 0;
 	for (FrameStream& f : frame_streams_) f.upload_seen = 0;
 	return 0;
@@ -603,6 +605,7 @@ int Scene::preload_all() {
 	resident_bricks_ = total_bricks_;
 	staging_busy_ = false;
 	failed_ = false;
+	stream_batches_ = stream_host_ns_ = 0;
 	upload_seq_ = 0;
 	for (FrameStream& f : frame_streams_) f.upload_seen = 0;
 	return 0;
@@ -665,6 +668,7 @@ void Scene::drop_frame_streams() {
 // Stage the first `count` requests of a ring (positions already in its pinned mirror), copy them up and scatter
 // them into the arena / index grid on the load stream (Scene.cpp:215-229 + the upload kernel, kernel.cu:141-151,412-413).
 int Scene::service_ring(int ring, uint32_t count) {
+	const auto t_host0 = std::chrono::steady_clock::now();
 	const WorldDims& d = world.dims;
 	const int* pos = h_positions_[ring];
 	// ---- pass 1: nothing is mutated before every entry has been checked (the positions come back from device memory:
@@ -750,6 +754,8 @@ int Scene::service_ring(int ring, uint32_t count) {
 	staging_busy_ = true;
 	upload_seq_++;
 	resident_bricks_ += count;
+	stream_batches_++;
+	stream_host_ns_ += static_cast<uint64_t>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_host0).count());
 	return 0;
 }
 
@@ -824,6 +830,8 @@ int Scene::info(bm_scene_info* out) {
 	out->arena_copy_growths = arena_copy_growths_;
 	out->arena_virtual = arena_virtual_ ? 1 : 0;
 	out->failed = failed_ ? 1 : 0;
+	out->stream_batches = stream_batches_;
+	out->stream_host_ns = stream_host_ns_;
 	return 0;
 }
 
@@ -950,6 +958,14 @@ int Scene::sched_stats_read(bm_sched_stats* out) {
 	BM_HIP(hipDeviceSynchronize());
 	static_assert(sizeof(bm_sched_stats) == sizeof(DeviceCounters::sched) + sizeof(DeviceCounters::cycles), "scheduler stat blocks must match");
 	BM_HIP(hipMemcpy(out, reinterpret_cast<const char*>(d_counters_) + offsetof(DeviceCounters, sched), sizeof(bm_sched_stats), hipMemcpyDeviceToHost));
+	return 0;
+}
+
+int Scene::sched_detail_read(uint64_t* out8) {
+	if (!out8) { set_error("null argument"); return BM_EINVAL; }
+	BM_HIP(hipSetDevice(device_));
+	BM_HIP(hipDeviceSynchronize());
+	BM_HIP(hipMemcpy(out8, reinterpret_cast<const char*>(d_counters_) + offsetof(DeviceCounters, detail), 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
 	return 0;
 }
 

@@ -50,6 +50,7 @@ public:
 	int counters_read(bm_counters* out);
 	int counters_reset();
 	int sched_stats_read(bm_sched_stats* out);
+	int sched_detail_read(uint64_t* out8);
 
 	// Hooks for a frame issued by other code on this scene (the wavefront mode): begin_frame orders `stream` behind
 	// pending brick uploads and hands out the current device view; end_frame records the "frame done" event process_load_queue waits for.
@@ -135,6 +136,7 @@ private:
 	struct ArenaChunk { hipMemGenericAllocationHandle_t handle; size_t offset, bytes; };
 	std::vector<ArenaChunk> arena_chunks_;
 	uint64_t arena_growths_ = 0, arena_copy_growths_ = 0; // times the arena grew / grew by synchronise + copy
+	uint64_t stream_batches_ = 0, stream_host_ns_ = 0;    // upload batches since the last residency reset / host time staging them
 	int arena_open(uint64_t max_bricks);  // reserve the address range (once per world)
 	int arena_unmap_all();
 	void arena_close();

@@ -58,6 +58,12 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_PRIO_C
 #define BM_PRIO_C 0
 #endif
+#ifndef BM_XCD_TILES
+#define BM_XCD_TILES 0 // > 0: XCD-aware hand-out in super-tiles of this many 16x16-pixel tiles per side (see the refill code)
+#endif
+#ifndef BM_XCD_HWID
+#define BM_XCD_HWID 0
+#endif
 #ifndef BM_WORK_COUNTERS
 #define BM_WORK_COUNTERS 8
 #endif
@@ -139,7 +145,14 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	constexpr uint32_t kCounters = BM_WORK_COUNTERS, kCounterStride = 32; // one 128-byte line per counter
 	// (the wave index is the same in all 64 lanes; saying so keeps everything derived from it -- the counter in use, `work_left`,
 	// the loop's exit conditions -- in scalar registers and the scheduler loop's branches scalar)
+#if BM_XCD_TILES && BM_XCD_HWID
+	// the XCD this wave runs on, from the hardware (HW_REG_XCC_ID = 20, bits 3:0)
+	int my_counter = static_cast<int>(static_cast<uint32_t>(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11))) % kCounters);
+#elif BM_XCD_TILES
+	int my_counter = static_cast<int>(blockIdx.x % kCounters); // the workgroup's XCD (round-robin dispatch over the 8 XCDs)
+#else
 	int my_counter = static_cast<int>((blockIdx.x * 4u + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)))) % kCounters);
+#endif
 	int counters_done = 0;
 	// hang guard only (NaN directions): no wave needs more scheduler rounds than this
 	const long long round_budget = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fc.spp) + 1) * (fc.max_bounces + 2) *
@@ -151,6 +164,12 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	uint32_t runsA = 0, lanesA = 0, runsB = 0, lanesB = 0, runsC = 0, lanesC = 0, runsD = 0, lanesD = 0, runsJ = 0, lanesJ = 0; // wave-uniform scheduler statistics
 
 	unsigned long long cycA = 0, cycB = 0, cycC = 0, cycD = 0;
+	unsigned long long det[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // BM_PHASE_TIMING: DeviceCounters::detail
+#ifdef BM_PHASE_TIMING
+#define BM_MARK(k, tprev) do { const unsigned long long bm_now_ = __builtin_amdgcn_s_memtime(); det[k] += bm_now_ - tprev; tprev = bm_now_; } while (0)
+#else
+#define BM_MARK(k, tprev) do { } while (0)
+#endif
 	const unsigned long long t_begin = BM_TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
 	unsigned long long t_dry = 0ull; // when this wave found the ticket counters empty (BM_TIMED): the rest of its life is the drain
 
@@ -168,10 +187,22 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			uint32_t base = 0;
 			if (lane == 0) base = atomicAdd(work_counter + my_counter * kCounterStride, static_cast<uint32_t>(want));
 			base = __builtin_amdgcn_readfirstlane(base);
+#if BM_XCD_TILES
+			// XCD-aware hand-out: the image is cut into super-tiles of BM_XCD_TILES x BM_XCD_TILES tiles (16x16 pixels each), super-tile
+			// st belongs to counter st % kCounters, and a wave starts on the counter of ITS XCD (workgroups go round-robin over the
+			// 8 XCDs, so blockIdx % 8 names the L2): the rays of neighbouring pixels -- which read the same field rows, index words
+			// and bricks -- are traced behind ONE L2 instead of all eight.  Super-tiles are small enough (128 x 128 pixels) that
+			// every XCD gets its share of sky and terrain; a wave whose counter is used up helps the next one.
+			const uint32_t st_x = (static_cast<uint32_t>(fc.tiles_x) + BM_XCD_TILES - 1u) / BM_XCD_TILES, st_y = (static_cast<uint32_t>(fc.tiles_y) + BM_XCD_TILES - 1u) / BM_XCD_TILES;
+			const uint32_t total_st = st_x * st_y;
+			const uint32_t my_st = total_st > static_cast<uint32_t>(my_counter) ? (total_st - static_cast<uint32_t>(my_counter) + kCounters - 1u) / kCounters : 0u;
+			const uint32_t my_tickets = my_st * (BM_XCD_TILES * BM_XCD_TILES * 16u) * items_per_chunk;
+#else
 			const uint32_t total_groups = (total_chunks + 3u) >> 2;
 			const uint32_t my_groups = total_groups > static_cast<uint32_t>(my_counter)
 										   ? (total_groups - static_cast<uint32_t>(my_counter) + kCounters - 1u) / kCounters : 0u;
 			const uint32_t my_tickets = my_groups * 4u * items_per_chunk; // consecutive tickets = the samples of one chunk
+#endif
 			const uint32_t counter_now = static_cast<uint32_t>(my_counter);
 			if (base + want >= my_tickets) { // this counter is used up: move to the next one (helping out), or finish
 				my_counter = (my_counter + 1) % static_cast<int>(kCounters);
@@ -182,11 +213,20 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				const uint32_t item = base + static_cast<uint32_t>(rank / BM_ITEM_LANES);
 				const uint32_t ticket = item / items_per_chunk, item_sub = item - ticket * items_per_chunk;
 				const uint32_t item_sample = item_sub / kParts, part = item_sub % kParts; // (kParts == 1: part 0)
+#if BM_XCD_TILES
+				constexpr uint32_t kStChunks = BM_XCD_TILES * BM_XCD_TILES * 16u;
+				const uint32_t st = (ticket / kStChunks) * kCounters + counter_now, in_st = ticket % kStChunks;
+				const uint32_t tw = in_st >> 4, k = in_st & 15u;
+				const int tile_x = static_cast<int>((st % st_x) * BM_XCD_TILES + tw % BM_XCD_TILES);
+				const int tile_y = static_cast<int>((st / st_x) * BM_XCD_TILES + tw / BM_XCD_TILES);
+				if (item < my_tickets && tile_x < fc.tiles_x && tile_y < fc.tiles_y) {
+#else
 				const uint32_t chunk = ((ticket >> 2) * kCounters + counter_now) * 4u + (ticket & 3u);
 				if (item < my_tickets && chunk < total_chunks) {
 					const uint32_t tile = chunk >> 4, k = chunk & 15u;
 					const int tile_x = static_cast<int>(tile % static_cast<uint32_t>(fc.tiles_x));
 					const int tile_y = static_cast<int>(tile / static_cast<uint32_t>(fc.tiles_x));
+#endif
 					const int cx = static_cast<int>((k & 1u) | ((k >> 1) & 2u)), cy = static_cast<int>(((k >> 1) & 1u) | ((k >> 2) & 2u));
 					const uint32_t q = part * BM_ITEM_LANES + (static_cast<uint32_t>(rank) % BM_ITEM_LANES); // pixel of the 4x4 chunk
 					const int x = tile_x * 16 + cx * 4 + static_cast<int>(q & 3u);
@@ -236,6 +276,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				if (n_conn) { runsD++; lanesD += n_conn; } // "connect" statistics: passes that held shadow-ray results, and how many
 			}
 			// ================= phase C: shade the finished extend ray / generate the next primary ray, then set the new ray up
+			unsigned long long t_sub = t_phase;
+			(void)t_sub;
 			if (state == ST_NEED || state == ST_CONN) {
 				bool need_setup = false;
 				f3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f);
@@ -265,6 +307,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						ro = hitp; rd = bdir; r.n = pn; shadow = false; need_setup = true;
 					}
 				}
+				BM_MARK(0, t_sub); // connect
 				if (pstate == P_EXT_DONE) {
 					// ---- extend finished (kernel.cu:226-238); `hit <=> distance < VERY_FAR`
 					const bool is_hit = r.hit;
@@ -316,6 +359,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 							else { bounces++; ro = hitp; rd = bdir; r.n = pn; shadow = false; need_setup = true; }
 						}
 					}
+					BM_MARK(1, t_sub); // shade, hit branch (cone sample, bounce direction)
 					if (!is_hit || cast) {
 						const SkyView sv = sky_view(fc, view);
 						if (cast) {
@@ -338,6 +382,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						pstate = P_GEN;
 					}
 				}
+				BM_MARK(2, t_sub); // sky model (+ the tail of the shade block)
 				if (pstate == P_GEN) {
 					if (s >= s_end) {
 						// item finished: write the accumulator back (or add this sample's share) and wait for the next one
@@ -377,19 +422,27 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						need_setup = true;
 					}
 				}
+				BM_MARK(3, t_sub); // pixel hand-back + primary ray
 				if (need_setup) {
 					if (shadow) r.n = mk(0.f, 0.f, 0.f); // connect passes a zeroed normal (kernel.cu:338)
 					pstate = shadow ? P_SHD_DONE : P_EXT_DONE;
 					const int st = ray_setup<DBG>(sc, ro, rd, r, tally);
 					state = (st == ST_NEED && shadow) ? ST_CONN : st;
 				}
+				BM_MARK(4, t_sub); // ray set-up
 			}
 		} else if (phase == 1) {
 			if (BM_PRIO) __builtin_amdgcn_s_setprio(BM_PRIO_B);
 			if (BM_TIMED) { runsB++; lanesB += nB; }
 			// ================= phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask DDA, streaming request)
+#ifdef BM_PHASE_TIMING
+			uint32_t walk_trips = 0;
+			if (state == ST_CAND) {
+				int st = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick, &walk_trips);
+#else
 			if (state == ST_CAND) {
 				int st = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick);
+#endif
 #if BM_B_STEP
 				// a ray that passed through the brick makes its move out of the cell right here: it is the only thing it can do
 				// next, and near a surface the next cell is often a candidate again
@@ -397,6 +450,13 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 #endif
 				state = (st == ST_NEED && shadow) ? ST_CONN : st;
 			}
+#ifdef BM_PHASE_TIMING
+			{ // longest 8^3 walk of this pass (= its loop length) and the lanes' own walk lengths
+				uint32_t mx = walk_trips, sum = walk_trips;
+				for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; sum += __shfl_xor(sum, off, 64); }
+				if (mx) { det[5] += 1; det[6] += mx; det[7] += sum; }
+			}
+#endif
 		} else {
 			// ================= phase A: brick-grid walk; lanes that reach a non-empty cell or leave the grid wait.
 			// Walking lanes are of two kinds: ST_JUMP lanes have an empty cube of BM_JUMP_MIN cells or more ahead and cross
@@ -456,6 +516,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		cycD = t_dry ? t_end - t_dry : 0ull; // "connect" slot: time from the wave's last (failed) refill to its exit = the drain
 		const unsigned long long cy[8] = {cycA, cycB, cycC, cycD, t_end - t_begin, runsJ, lanesJ, 1ull};
 		for (int k = 0; k < 8; ++k) atomicAdd(&counters->cycles[k], cy[k]);
+		for (int k = 0; k < 8; ++k) atomicAdd(&counters->detail[k], det[k]);
 	}
 }
 

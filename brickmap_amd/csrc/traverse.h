@@ -97,7 +97,8 @@ __device__ __forceinline__ void brick_to_lds(unsigned long long* lds_brick, cons
 
 template <int N, bool DBG>
 __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy, int sz, float dx, float dy, float dz, f3& normal, float& distance,
-											   const BrickRegs& brick, uint32_t byte, int& sub_id, Tally& tally, unsigned long long* lds_brick = nullptr) {
+											   const BrickRegs& brick, uint32_t byte, int& sub_id, Tally& tally, unsigned long long* lds_brick = nullptr,
+											   uint32_t* trips = nullptr) {
 	int px = static_cast<int>(origin.x), py = static_cast<int>(origin.y), pz = static_cast<int>(origin.z);
 	const float cbx = dir.x > 0.f ? static_cast<float>(px + 1) : static_cast<float>(px);
 	const float cby = dir.y > 0.f ? static_cast<float>(py + 1) : static_cast<float>(py);
@@ -129,7 +130,8 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 	bool inside = true;
 	int last = 0; // packed increment of the last move: which axis it was
 	// at most 3N-2 cells lie on a line through an N^3 block; the bound only guards against NaN input
-	for (int guard = 3 * N + 1; !solid && inside && guard > 0; --guard) {
+	int guard = 3 * N + 1;
+	for (; !solid && inside && guard > 0; --guard) {
 		// select-style move (voxel.cuh:122-130); `t += mask ? delta : 0` is `tmax += mask * tdelta` for finite deltas
 #if BM_CMP3
 		const bool xy = tx < ty; // for ordered operands ty <= tx is !(tx < ty): three compares instead of four (a NaN tmax makes no
@@ -150,6 +152,7 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 		if (DBG && inside) tally.voxel_steps++;
 		solid = static_cast<bool>(static_cast<int>(inside) & static_cast<int>(test(cell, slice))); // no branch: (cell's fields are masked, any value is safe to test)
 	}
+	if (trips) *trips = static_cast<uint32_t>(3 * N + 2 - guard); // profiling builds: cells tested by this lane
 	if (!solid) return false;
 	// voxel.cuh:114-118, by select; a hit in the very first cell (no move) keeps distance 0 and the caller's normal
 	const int a = last < 0 ? -last : last; // 0 = no move, 1 = x, 32 = y, 1024 = z
@@ -423,7 +426,7 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 // voxel.cuh:200-247: the current cell holds a non-empty brick -- read its index word and resolve it.
 template <bool DBG>
 __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const int* campos, RayState& r, HitInfo& info, Tally& tally,
-													 unsigned long long* lds_brick) {
+													 unsigned long long* lds_brick, uint32_t* walk_trips = nullptr) {
 	const int px = cell_x(r.p), py = cell_y(r.p), pz = cell_z(r.p);
 	const int sx = r.sx, sy = r.stepy >> 11, sz = r.stepz >> 22; // step signs back from the packed increments
 	// inside the grid 0 <= pos < cells, so >>4 and &15 equal the reference's signed /16 and %16
@@ -478,7 +481,7 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 		brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
 #endif
 		const f3 o8 = (r.o + r.d * new_distance) * 8.f - r.n * kEpsilon;
-		if (intersect_grid<8, DBG>(o8, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick)) {
+		if (intersect_grid<8, DBG>(o8, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick, walk_trips)) {
 			r.distance = new_distance * 8.f + sub_distance + r.tminn;
 			if (DBG) { info.level = 2; info.sub_id = sub; }
 			r.hit = true;

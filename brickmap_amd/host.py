@@ -17,8 +17,8 @@ from ._lib import bm_camera, bm_counters, bm_frame_params, bm_scene_info, check
 
 
 # The reference's fly-through presets (performance_measure.h:4-25): camera position + (horizontal, vertical) angle.
-# It lists 9 positions but only 8 angle pairs (and indexes both with the same counter, performance_measure.cpp:74-76);
-# the 8 complete pairs are kept.  World: the reference's native 4096 x 4096 x 512 voxels.
+# It lists 9 positions but only 8 angle pairs and indexes both with the same counter (performance_measure.cpp:32-34).
+# World: the reference's native 4096 x 4096 x 512 voxels.
 FLYTHROUGH_VIEWS = (
     ((512.0, 512.0, 300.0), (-61863.5, -0.501796)),
     ((840.254, 832.446, 1169.88), (-61864.4, -0.429796)),
@@ -28,6 +28,9 @@ FLYTHROUGH_VIEWS = (
     ((11298.6, 3113.03, 598.019), (-61866.3, -0.141796)),
     ((10921.4, 4774.14, 267.808), (-61859.4, 0.0142036)),
     ((9961.29, 4508.12, 189.59), (-61857.2, -0.261796)),
+    # the 9th position has no angle pair of its own: the reference reads test_angles[8] past the end of the vector
+    # (performance_measure.cpp:33-34, undefined behaviour); here it is flown with the last defined pair
+    ((10835.3, 4160.83, 359.992), (-61857.2, -0.261796)),
 )
 
 
@@ -257,6 +260,13 @@ class Scene:
         st = _lib.bm_sched_stats()
         check(self._L.bm_sched_stats_read(self.gpuScene, C.byref(st)))
         return {n: int(getattr(st, n)) for n in _lib.SCHED_NAMES}
+
+    def sched_detail(self):
+        """-DBM_PHASE_TIMING builds: time split of the shade pass and loop lengths of the candidate pass (bm_sched_detail_read)."""
+        out = (C.c_uint64 * 8)()
+        check(self._L.bm_sched_detail_read(self.gpuScene, out))
+        names = ("connect_cycles", "shade_hit_cycles", "sky_cycles", "primary_cycles", "setup_cycles", "brick_passes", "brick_loop_trips", "brick_lane_steps")
+        return dict(zip(names, (int(v) for v in out)))
 
     def counters_reset(self):
         check(self._L.bm_counters_reset(self.gpuScene))

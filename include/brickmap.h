@@ -92,6 +92,8 @@ typedef struct bm_scene_info {
 	                                   address range that physical chunks are mapped into (arena_virtual)                        */
 	int32_t arena_virtual;          /* 1: hipMemAddressReserve / hipMemMap arena (grows without copy or synchronisation)          */
 	int32_t failed;                 /* 1: a streaming batch could not be completed; frames are refused until the residency is reset */
+	uint64_t stream_batches;        /* upload batches queued since the residency was last reset                                   */
+	uint64_t stream_host_ns;        /* host time spent staging them (validate, copy bricks to pinned memory, hand out slots, queue) */
 } bm_scene_info;
 
 /* traversal counters (BM_FLAG_COUNTERS); same order as oracle/oracle.c orc_counters */
@@ -210,6 +212,10 @@ BM_API int bm_render_times(bm_scene* scene, float* ms, int capacity, int* count)
 BM_API int bm_counters_read(bm_scene* scene, bm_counters* out);
 BM_API int bm_counters_reset(bm_scene* scene);
 BM_API int bm_sched_stats_read(bm_scene* scene, bm_sched_stats* out);
+/* profiling builds (-DBM_PHASE_TIMING) only, zeros otherwise.  out8 = shader-clock ticks, summed over waves, a shade pass spends
+ * in: connect, shade (hit branch), the sky model, pixel hand-back + primary ray, ray set-up; then the candidate passes that
+ * walked an 8^3 brick, the sum of their loop lengths (longest walk among the lanes of the pass) and the sum of all lanes' walk lengths */
+BM_API int bm_sched_detail_read(bm_scene* scene, uint64_t* out8);
 
 /* ---- wavefront mode: launch_kernels exactly as the reference schedules it (kernel.cu:366-439) --
  * one call traces ONE segment of every path in flight: primary_rays tops the work queue up to `queue_size`

@@ -557,6 +557,9 @@ static int intersect_grid(v3 origin, v3 direction, v3* normal, float* distance, 
 	return 0;
 }
 
+typedef void (*orc_brick_probe_t)(const float* origin_in_brick, const float* direction, uint32_t index_word, const uint32_t* brick16, int hit, unsigned steps);
+static orc_brick_probe_t orc_brick_probe_fn = 0;
+ORC_API void orc_set_brick_probe(orc_brick_probe_t fn) { orc_brick_probe_fn = fn; }
 static int intersect_voxel(orc_world* w, v3 origin, const v3 direction, v3* normal, float* distance, i3 camera_position, orc_hit* hit, orc_counters* cnt, int atomic_requests) { /* :135-261 */
 	float tminn;
 	hit->hit = 0; hit->level = 0; hit->brick_id = -1; hit->sub_id = 0;
@@ -639,7 +642,14 @@ static int intersect_voxel(orc_world* w, v3 origin, const v3 direction, v3* norm
 					cnt->brick_tests++;
 					v3 o8 = sub3(muls(add3(origin, muls(direction, new_distance)), 8.f), muls(*normal, k_epsilon));
 					int sub = 0;
-					if (intersect_grid(o8, direction, normal, &sub_distance, 8, brick, &sub, cnt)) {
+					const uint64_t steps_before = cnt->voxel_steps;
+					const int brick_hit = intersect_grid(o8, direction, normal, &sub_distance, 8, brick, &sub, cnt);
+					if (orc_brick_probe_fn) { /* analysis door (tools/sim): one call per 8^3 test */
+						const float po[3] = { o8.x - 8.f * (float)pos.x, o8.y - 8.f * (float)pos.y, o8.z - 8.f * (float)pos.z };
+						const float pd[3] = { direction.x, direction.y, direction.z };
+						orc_brick_probe_fn(po, pd, index, brick, brick_hit, (unsigned)(cnt->voxel_steps - steps_before));
+					}
+					if (brick_hit) {
 						*distance = new_distance * 8.f + sub_distance + tminn;
 						hit->hit = 1; hit->level = 2; hit->brick_id = brick_id; hit->sub_id = sub;
 						return 1;

@@ -1,5 +1,5 @@
 """The reference's fly-through (performance_measure.h:4-25) on its native world (4096 x 4096 x 512 voxels, all bricks
-resident): ms per 1920x1080 frame (1 spp, 4 segments) for each of the 8 viewpoints -- the regression scene of
+resident): ms per 1920x1080 frame (1 spp, 4 segments) for each of the 9 viewpoints -- the regression scene of
 SURVEY.md section 8(f) item 3.  Usage (GPU box): python tools/flythrough.py [frames_per_view]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -8,8 +8,11 @@ writes, under gpurun_out/ (copy what is to be judged into profiles/):
   <tag>_kernel_stats_<workload>.csv    rocprofv3 --kernel-trace --stats summary of the SAME command
   <tag>_pmc_summary_<workload>.json    per-launch averages of bm::trace_paths<false> from separate --pmc passes (kernel-trace
                                        only, one counter group per pass) + the derived figures DESIGN.md quotes
-Counter units / corrections as MI355X_MICROARCH.md prescribes: FETCH_SIZE, WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts a
-128-byte request as 64 bytes, so it is doubled; WRITE_SIZE as reported.
+Counter units / corrections: FETCH_SIZE, WRITE_SIZE in KiB.  On gfx950 FETCH_SIZE = fabric read requests x 64 B; MI355X_MICROARCH.md
+prescribes x2 for full-line (128-byte) coalesced streams and says other patterns must be calibrated -- done in
+profiles/r03_fetch_calibration.txt (tools/ubench/fetch_calib.hip): every access of trace_paths (1-byte field lookups, 4-byte
+index words, 64-byte bricks) is a single-SECTOR request, for which FETCH_SIZE is exact as reported: factor 1.0.  MALL hits
+are included (the counters cannot separate them).  WRITE_SIZE as reported.
 """
 import collections
 import csv
@@ -23,6 +26,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 KERNEL = "trace_paths<false>"
+FETCH_FACTOR = 1.0  # profiles/r03_fetch_calibration.txt: single-sector requests are counted at their true 64 bytes
 PMC_SETS = [
     "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY",
     "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_WR",
@@ -79,10 +83,12 @@ def main():
     for c in sorted(tot):
         s[c + ("_KiB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")] = tot[c] / n[c]
     if "FETCH_SIZE_KiB" in s and "WRITE_SIZE_KiB" in s:
-        hbm = (2.0 * s["FETCH_SIZE_KiB"] + s["WRITE_SIZE_KiB"]) * 1024
+        hbm = (FETCH_FACTOR * s["FETCH_SIZE_KiB"] + s["WRITE_SIZE_KiB"]) * 1024
         ms = bench_json["roofline"]["kernel_ms_avg"]
         s["derived"] = {
-            "hbm_bytes_per_launch (2 x FETCH + WRITE)": hbm,
+            "fabric_bytes_per_launch (1.0 x FETCH + WRITE; sector requests, MALL hits included)": hbm,
+            "sector_requests_per_s_G": (s["TCC_MISS"] / (ms * 1e-3) / 1e9) if s.get("TCC_MISS") else None,
+            "frac_of_measured_random_sector_ceiling (48 G requests/s)": (s["TCC_MISS"] / (ms * 1e-3) / 48e9) if s.get("TCC_MISS") else None,
             "kernel_ms_avg (bench, HIP events)": ms,
             "kernel_ms_avg (rocprofv3 --stats)": kernel_avg_ns / 1e6 if kernel_avg_ns else None,
             "hbm_GBps": hbm / (ms * 1e-3) / 1e9,
