@@ -634,10 +634,13 @@ int Scene::frame_begin(hipStream_t stream) {
 		frame_streams_.push_back(f);
 		fs = &frame_streams_.back();
 	}
-	if (fs->upload_seen < upload_seq_) {
+	// (a stream handle can be recycled by the runtime after its owner destroyed it: an entry that claims to have seen the
+	// latest batch is only trusted once that batch has actually completed)
+	if (fs->upload_seen < upload_seq_ || (upload_seq_ > 0 && hipEventQuery(ev_upload_) == hipErrorNotReady)) {
 		BM_HIP(hipStreamWaitEvent(stream, ev_upload_, 0)); // ev_upload_ is re-recorded behind every batch: waiting for it covers all earlier ones
 		fs->upload_seen = upload_seq_;
 	}
+	(void)hipGetLastError(); // hipErrorNotReady is a status, not a failure
 	fs->last_use = ++frame_seq_;
 	return 0;
 }
