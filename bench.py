@@ -368,6 +368,8 @@ def main():
             torch.cuda.synchronize()
             same_job = {"error": repr(e)}
 
+    if multi:
+        dist.barrier()  # rank 0's untimed extras are done: every rank leaves the process group together
     if rank != 0:
         if multi:
             dist.destroy_process_group()

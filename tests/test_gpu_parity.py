@@ -747,6 +747,43 @@ def test_arena_grows_without_stopping_the_world(bm, orc, torch_cuda):
     scene.close()
 
 
+def test_arena_fallback_without_virtual_memory(bm, torch_cuda):
+    """Devices without hipMemAddressReserve / hipMemMap reallocate + copy the arena behind a device synchronisation; the path is
+    kept alive here by switching virtual memory management off (BM_ARENA_VMM=0) in a child process: the 2048^3 world streams in,
+    the arena grows by copying, and the steady-state frame equals the same frame of a scene with the mapped arena."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import brickmap_amd as bm
+G, W, H = 2048, 640, 360
+s = bm.Scene(G, G, device=0); s.set_queue_capacity(1 << 18); s.generate()
+cam = bm.Camera(position=(G / 2, G / 8, 0.8 * G), horizontal_angle=0.8, vertical_angle=-0.5).update()
+acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+p = bm.FrameParams(W, H, spp=2, max_bounces=7)
+idle = 0
+for k in range(400):
+    s.render(cam, p, acc)
+    idle = idle + 1 if s.process_load_queue() == 0 else 0
+    if idle >= 2: break
+assert idle >= 2
+i = s.info()
+out = torch.zeros_like(acc); s.render(cam, p, out); torch.cuda.synchronize()
+print("RESULT", i["arena_virtual"], i["arena_growths"], i["arena_copy_growths"], i["resident_bricks"], float(out.double().sum().item()))
+""" % root
+    results = []
+    for vmm in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, BM_ARENA_VMM=vmm), cwd=root)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+        results.append([l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()[1:])
+    (v0, g0, c0, n0, sum0), (v1, g1, c1, n1, sum1) = results
+    assert v0 == "0" and int(g0) >= 1 and int(c0) == int(g0)  # fallback: every growth copied
+    assert v1 == "1" and int(g1) >= 1 and int(c1) == 0        # mapped arena: none did
+    assert n0 == n1 and sum0 == sum1                            # same residency, same frame
+
+
 def test_overlapped_streaming_reaches_the_resident_image(bm, orc, torch_cuda):
     """Overlapped request servicing (two rings, no host wait): same steady state as the all-resident scene, every
     brick uploaded exactly once, requests land two calls after they were raised."""
