@@ -45,3 +45,26 @@ def test_bench_multi_gpu_code_path_on_nccl_with_one_rank(extra):
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["scaling"] == "strong" and out["config"]["spp_per_step"] == 8
     assert out["verified_against_single_gpu"]["frames"] == 5 and out["verified_against_single_gpu"]["max_rel_err"] < 1e-5
     assert out["same_job_single_gpu"]["ms_per_step"] > 0 and "cpu_baseline" not in out
+
+
+def test_default_bench_line_schema():
+    """The N = 1 line the driver records: the contract's keys plus `roofline` (with what `achieved` is and what limits the
+    kernel), the same-job figure the N > 1 lines scale against, and no process group (one rank, no RCCL)."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BM_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["unit"] == "Mrays/s" and out["dtype"] == "f32" and out["vs_baseline"] is None
+    assert "1920x1080" in out["config"]["workload"] and out["config"]["spp_per_step"] == 1
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    assert "reference-equivalent" in rf["achieved_is"] and "VALU" in rf["limiter"] and rf["kernel_ms_avg"] <= out["ms_per_step"] * 1.05
+    assert rf["traffic"] and "r03_pmc_summary_config2.json" in rf["traffic_source"]
+    assert out["multi_gpu_job_on_one_gpu"]["ms_per_step"] > 0 and out["north_star_4spp"]["roofline_frac"] > 0 and out["pipelined"]["ms_per_step"] > 0
