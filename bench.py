@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # what bounds trace_paths on each workload (profiles/r03_pmc_summary_<workload>.json, profiles/r03_fetch_calibration.txt)
 LIMITER = {
     "config1": "launch latency (a 256x256 frame is 65 k paths: less than one wave-load per SIMD)",
-    "config2": "VALU issue: the vector pipes are busy for the whole launch with ~20 of 64 lanes active per instruction; the scene (93 MiB) stays in L2 / Infinity Cache",
+    "config2": "VALU issue: the vector pipes are busy for >= 85 % of the launch with ~20 of 64 lanes active per instruction; the scene (93 MiB) stays in L2 / Infinity Cache",
     "config3": "VALU issue, with 0.6 G L2 sector misses per launch (TCC hit 61 %)",
     "config4": "VALU issue, with 0.6 G L2 sector misses per launch (TCC hit 61 %)",
     "config5": "fabric request rate: 41.5 G single-sector (64 B) read requests/s, 85 % of the 48 G/s this GPU sustains for random sectors (= 3.1 TB/s, not the 8 TB/s byte peak)",
