@@ -334,6 +334,8 @@ int Scene::arena_unmap_all() {
 
 void Scene::arena_close() {
 	if (arena_virtual_) {
+		// unlike hipFree, unmapping does not wait for work that still uses the range
+		if (!arena_chunks_.empty()) (void)hipDeviceSynchronize();
 		(void)arena_unmap_all();
 		if (d_arena_) (void)hipMemAddressFree(d_arena_, arena_va_bytes_);
 	} else if (d_arena_) {
@@ -358,6 +360,7 @@ int Scene::arena_reserve(uint64_t bricks, bool exact) {
 		auto round_up = [gran](uint64_t b) { return (b + gran - 1) / gran * gran; };
 		uint64_t want_bytes;
 		if (exact && arena_top_ == 0) {
+			if (!arena_chunks_.empty()) BM_HIP(hipDeviceSynchronize()); // (callers have synchronised already; unmapping itself does not wait)
 			if (int e = arena_unmap_all()) return e;
 			want_bytes = round_up(std::max<uint64_t>(bricks, 1ull << 16) * sizeof(Brick));
 		} else {
