@@ -13,6 +13,9 @@
 #ifndef BM_FIELD_BLOCKED
 #define BM_FIELD_BLOCKED 0 // 1: cube field in 4x4x4-cell blocks of 64 bytes (scene.cpp lays it out accordingly)
 #endif
+#ifndef BM_LOD_PRETEST
+#define BM_LOD_PRETEST 0 // 1: candidates are pre-tested against the index word's 2^3 LoD byte before their brick is fetched (process_candidate)
+#endif
 #ifndef BM_NT_BRICKS
 #define BM_NT_BRICKS 0 // 1: the 64-byte brick is fetched with non-temporal loads (it is used once; keeps field lines in the L2)
 #endif
@@ -468,6 +471,31 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	} else if (index & kLoadedBit) {
 		if (DBG) tally.brick_tests++;
 		int sub = 0;
+		const f3 o8 = (r.o + r.d * new_distance) * 8.f - r.n * kEpsilon;
+		bool walk = true, pretest_skip = false;
+#if BM_LOD_PRETEST
+		// Conservative pre-test against the 2^3 LoD byte of the index word (Scene.cpp:95: bit xb + 2 yb + 4 zb = "the 4^3 sub-block holds
+		// a voxel"): the exact walk only visits voxels within ~1e-5 voxel of the chord from the entry point to the point where the
+		// ray leaves the brick, so if no occupied sub-block overlaps the chord's bounding box grown by 0.01 voxel, the walk cannot
+		// find a voxel and the 64-byte brick need not be fetched.  Only when the walk's start voxel lies inside the brick (a start
+		// cell just outside wraps around in the reference, `pos % 8`, voxel.cuh:96-101); NaNs select every sub-block.  The
+		// instrumented kernel always walks (its counters are the reference's) and poisons the hit record if a skipped brick was hit.
+		{
+			const float pox = o8.x - static_cast<float>(px * 8), poy = o8.y - static_cast<float>(py * 8), poz = o8.z - static_cast<float>(pz * 8);
+			const bool in = pox >= 0.f && pox < 8.f && poy >= 0.f && poy < 8.f && poz >= 0.f && poz < 8.f;
+			const float ex = r.d.x > 0.f ? (8.f - pox) * r.dx : (r.d.x < 0.f ? pox * r.dx : 1e30f);
+			const float ey = r.d.y > 0.f ? (8.f - poy) * r.dy : (r.d.y < 0.f ? poy * r.dy : 1e30f);
+			const float ez = r.d.z > 0.f ? (8.f - poz) * r.dz : (r.d.z < 0.f ? poz * r.dz : 1e30f);
+			const float te = fmaxf(fminf(fminf(ex, ey), ez), 0.f);
+			const float qx = pox + r.d.x * te, qy = poy + r.d.y * te, qz = poz + r.d.z * te;
+			const uint32_t xm = (!(fminf(pox, qx) - 0.01f >= 4.f) ? 0x55u : 0u) | (!(fmaxf(pox, qx) + 0.01f < 4.f) ? 0xAAu : 0u);
+			const uint32_t ym = (!(fminf(poy, qy) - 0.01f >= 4.f) ? 0x33u : 0u) | (!(fmaxf(poy, qy) + 0.01f < 4.f) ? 0xCCu : 0u);
+			const uint32_t zm = (!(fminf(poz, qz) - 0.01f >= 4.f) ? 0x0Fu : 0u) | (!(fmaxf(poz, qz) + 0.01f < 4.f) ? 0xF0u : 0u);
+			pretest_skip = in && ((((index & kLodBits) >> 12) & xm & ym & zm) == 0u);
+			if (!DBG) walk = !pretest_skip;
+		}
+#endif
+		if (walk) {
 		const uint4* bq = reinterpret_cast<const uint4*>(sc.brick_arena + (static_cast<size_t>(pool + (index & kIndexBits)) << 4));
 #if BM_NT_BRICKS
 		{
@@ -480,12 +508,12 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 #else
 		brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
 #endif
-		const f3 o8 = (r.o + r.d * new_distance) * 8.f - r.n * kEpsilon;
 		if (intersect_grid<8, DBG>(o8, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick, walk_trips)) {
 			r.distance = new_distance * 8.f + sub_distance + r.tminn;
-			if (DBG) { info.level = 2; info.sub_id = sub; }
+			if (DBG) { info.level = 2; info.sub_id = pretest_skip ? (sub | 0x4000) : sub; } // (poison: the pre-test would have dropped a hit)
 			r.hit = true;
 			return ST_NEED;
+		}
 		}
 	} else if (index & kUnloadedBit) {
 		// brick-request protocol (voxel.cuh:228-245): 32-bit atomics on the index word and the ring counter
