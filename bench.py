@@ -47,7 +47,7 @@ LIMITER = {
     "config2": "VALU issue: the vector pipes are busy for >= 85 % of the launch with ~20 of 64 lanes active per instruction; the scene (93 MiB) stays in L2 / Infinity Cache",
     "config3": "VALU issue, with 0.6 G L2 sector misses per launch (TCC hit 61 %)",
     "config4": "VALU issue, with 0.6 G L2 sector misses per launch (TCC hit 61 %)",
-    "config5": "fabric request rate: 41.5 G single-sector (64 B) read requests/s, 85 % of the 48 G/s this GPU sustains for random sectors (= 3.1 TB/s, not the 8 TB/s byte peak)",
+    "config5": "two limits at once: 41.5 G single-sector (64 B) read requests/s = 0.86 of the 48 G/s the fabric sustains for random sectors (3.1 TB/s, not the 8 TB/s byte peak), and VALU issue (vector pipes full at ~18 of 64 lanes per instruction)",
 }
 PROFILE_ROUND = "r03"  # profiles/<round>_pmc_summary*.json is where roofline.traffic comes from
 
