@@ -190,6 +190,9 @@ int Scene::init(int grid_size, int grid_height) {
 	compute_units_ = prop.multiProcessorCount; // main.cpp:97 sm_cores
 	blocks_per_cu_[0] = trace_blocks_per_cu(false);
 	blocks_per_cu_[1] = trace_blocks_per_cu(true);
+	blocks_per_cu_k_[0] = trace_k_blocks_per_cu(false);
+	blocks_per_cu_k_[1] = trace_k_blocks_per_cu(true);
+	if (const char* sch = std::getenv("BM_SCHEDULE")) kslot_default_ = std::strcmp(sch, "kslot") == 0;
 	if (const char* cap = std::getenv("BM_TRACE_BLOCKS_PER_CU")) { // experiment knob: fewer resident waves per SIMD (1 block = 1 wave per SIMD)
 		const int n = std::atoi(cap);
 		if (n > 0 && n < blocks_per_cu_[0]) blocks_per_cu_[0] = n;
@@ -629,6 +632,7 @@ int Scene::frame_begin(hipStream_t stream) {
 			for (size_t i = 1; i < frame_streams_.size(); ++i) if (frame_streams_[i].last_use < frame_streams_[lru].last_use) lru = i;
 			BM_HIP(hipEventSynchronize(frame_streams_[lru].done));
 			BM_HIP(hipEventDestroy(frame_streams_[lru].done));
+			if (frame_streams_[lru].kslot_scratch) (void)hipFree(frame_streams_[lru].kslot_scratch);
 			frame_streams_.erase(frame_streams_.begin() + static_cast<long>(lru));
 		}
 		FrameStream f;
@@ -666,7 +670,10 @@ int Scene::order_load_stream_behind_frames() {
 }
 
 void Scene::drop_frame_streams() {
-	for (FrameStream& f : frame_streams_) if (f.done) (void)hipEventDestroy(f.done);
+	for (FrameStream& f : frame_streams_) {
+		if (f.done) (void)hipEventDestroy(f.done);
+		if (f.kslot_scratch) (void)hipFree(f.kslot_scratch);
+	}
 	frame_streams_.clear();
 }
 
@@ -888,8 +895,23 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 #else
 	DeviceCounters* const counters_arg = (fp->flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr;
 #endif
-	launch_trace(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, work_counter, instrumented,
-				 compute_units_ * blocks_per_cu_[instrumented ? 1 : 0], stream);
+	if (kslot_default_ || (fp->flags & BM_FLAG_KSLOT)) {
+		// K-slot schedule: the launch keeps its path records in a scratch buffer of the stream it runs on
+		const int resident = compute_units_ * blocks_per_cu_k_[instrumented ? 1 : 0];
+		const size_t need = trace_k_scratch_bytes(instrumented, resident);
+		FrameStream* fs = nullptr;
+		for (FrameStream& f : frame_streams_) if (f.stream == stream) { fs = &f; break; }
+		if (!fs) { set_error("frame stream missing"); return BM_ESTATE; }
+		if (fs->kslot_scratch_bytes < need) {
+			if (fs->kslot_scratch) { BM_HIP(hipStreamSynchronize(stream)); BM_HIP(hipFree(fs->kslot_scratch)); fs->kslot_scratch = nullptr; fs->kslot_scratch_bytes = 0; }
+			BM_HIP(hipMalloc(&fs->kslot_scratch, need));
+			fs->kslot_scratch_bytes = need;
+		}
+		launch_trace_k(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, work_counter, instrumented, resident, fs->kslot_scratch, stream);
+	} else {
+		launch_trace(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, work_counter, instrumented,
+					 compute_units_ * blocks_per_cu_[instrumented ? 1 : 0], stream);
+	}
 	BM_HIP(hipGetLastError());
 	BM_HIP(hipEventRecord(ev_stop_[slot], stream));
 	if (int e = frame_end(stream)) return e; // what process_load_queue orders itself behind

@@ -262,6 +262,10 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		const int quorum = (live * BM_QUORUM_NUM + BM_QUORUM_DIV - 1) / BM_QUORUM_DIV;
 		const int quorum_shade = (live * BM_QUORUM_SHADE_NUM + BM_QUORUM_SHADE_DIV - 1) / BM_QUORUM_SHADE_DIV;
 		int phase; // 0 = A (DDA moves), 1 = B (candidates), 2 = C (shade / generate), 3 = D (connect)
+#ifdef BM_ARGMAX_WB
+		if (true) { const int vA = nA * 4, vB = nB * BM_ARGMAX_WB, vC = nC * BM_ARGMAX_WC; phase = (vC >= vA && vC >= vB) ? 2 : (vB >= vA ? 1 : 0); }
+		else
+#endif
 		if (nC >= quorum_shade) phase = 2;
 		else if (nB >= quorum) phase = 1;
 		else if (nA > 0) phase = 0;

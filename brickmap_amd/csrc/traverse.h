@@ -98,7 +98,14 @@ __device__ __forceinline__ void brick_to_lds(unsigned long long* lds_brick, cons
 	lds_brick[7 * 256 + t] = static_cast<unsigned long long>(b.q3.z) | (static_cast<unsigned long long>(b.q3.w) << 32);
 }
 
-template <int N, bool DBG>
+// OVERLAY (trace_k.hip): the brick is staged in four 16-byte chunks 4 KiB apart that belong to the calling thread alone
+// (`lds_brick` points at the first): slice z is the 64-bit half (z & 1) of chunk z >> 1.
+template <bool OVERLAY>
+__device__ __forceinline__ unsigned long long brick_slice(const unsigned long long* lds_brick, uint32_t z) {
+	if (OVERLAY) return lds_brick[(z >> 1) * 512u + (z & 1u)];
+	return lds_brick[z * 256u + threadIdx.x];
+}
+template <int N, bool DBG, bool OVERLAY = false>
 __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy, int sz, float dx, float dy, float dz, f3& normal, float& distance,
 											   const BrickRegs& brick, uint32_t byte, int& sub_id, Tally& tally, unsigned long long* lds_brick = nullptr,
 											   uint32_t* trips = nullptr) {
@@ -121,13 +128,19 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 	constexpr uint32_t kGuard = (~static_cast<uint32_t>(N - 1) & 0x1Fu) * kOnes, kInside = 8u * kOnes;
 	uint32_t cell = ((static_cast<uint32_t>(px % N) & (N - 1)) | ((static_cast<uint32_t>(py % N) & (N - 1)) << 5) | ((static_cast<uint32_t>(pz % N) & (N - 1)) << 10)) + kInside;
 	const int step_x = sx, step_y = sy * 32, step_z = sz * 1024;
-	const int lds_lane = threadIdx.x;
 	auto test = [&](uint32_t c, unsigned long long slice) -> bool {
 		if (N == 8) return static_cast<uint32_t>(slice >> ((c & 7u) | ((c >> 2) & 0x38u))) & 1u;          // bit x + 8y of the z-slice
 		return (byte >> ((c & 1u) | ((c >> 4) & 2u) | ((c >> 8) & 4u))) & 1u;                                  // bit x + 2y + 4z of the LoD mask
 	};
-	if (N == 8) brick_to_lds(lds_brick, brick);
-	unsigned long long slice = N == 8 ? lds_brick[((cell >> 10) & 7u) * 256 + lds_lane] : 0ull;
+	if (N == 8) {
+		if (OVERLAY) {
+			uint4* q = reinterpret_cast<uint4*>(lds_brick);
+			q[0] = brick.q0; q[256] = brick.q1; q[512] = brick.q2; q[768] = brick.q3;
+		} else {
+			brick_to_lds(lds_brick, brick);
+		}
+	}
+	unsigned long long slice = N == 8 ? brick_slice<OVERLAY>(lds_brick, (cell >> 10) & 7u) : 0ull;
 	if (DBG) tally.voxel_steps++;
 	bool solid = test(cell, slice);
 	bool inside = true;
@@ -151,7 +164,7 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 		tx += mx ? dx : 0.f;
 		ty += my ? dy : 0.f;
 		tz += mz ? dz : 0.f;
-		if (N == 8) slice = lds_brick[((cell >> 10) & 7u) * 256 + lds_lane];
+		if (N == 8) slice = brick_slice<OVERLAY>(lds_brick, (cell >> 10) & 7u);
 		if (DBG && inside) tally.voxel_steps++;
 		solid = static_cast<bool>(static_cast<int>(inside) & static_cast<int>(test(cell, slice))); // no branch: (cell's fields are masked, any value is safe to test)
 	}
@@ -183,6 +196,7 @@ struct RayState {
 	float tminn;
 	f3 n;               // normal carried in/out of the traversal (voxel.cuh:135 `normal`)
 	int last_step;      // packed-cell increment of the last move (0 before the first): which axis it was, see move_axis
+	int last_axis;      // the same as an axis number (-1 before the first move): what trace_k.hip keeps instead of last_step
 	uint32_t field_off;      // byte offset of the ray's octant plane in DeviceScene::cube_field
 	uint32_t cube;           // edge of the empty cube ahead of the current cell (its cube_field byte)
 	float distance;     // result
@@ -265,6 +279,7 @@ __device__ __forceinline__ int field_step(const DeviceScene& sc, RayState& r, Ta
 	const int step = mx ? step_x : (my ? step_y : step_z);
 	r.p += static_cast<uint32_t>(step);
 	r.last_step = step;
+	r.last_axis = mx ? 0 : (my ? 1 : 2);
 	r.tx = tx + (mx ? r.dx : 0.f);
 	r.ty = ty + (my ? r.dy : 0.f);
 	r.tz = tz + (mz ? r.dz : 0.f);
@@ -316,6 +331,7 @@ __device__ __forceinline__ int field_jump(const DeviceScene& sc, RayState& r, Ta
 	// all three products fit 24-bit signed multiplies: counts <= 255, increments +-1 / +-2^11 / +-2^22
 	r.p += static_cast<uint32_t>(__mul24(static_cast<int>(cx), step_x) + __mul24(static_cast<int>(cy), step_y) + __mul24(static_cast<int>(cz), step_z));
 	r.last_step = axis == 0 ? step_x : (axis == 1 ? step_y : step_z); // (only read after a cube exit, where it is the exit axis)
+	r.last_axis = axis;
 	const int st = field_lookup(sc, r);
 	if (DBG) tally.index_loads += cx + cy + cz - (st == ST_NEED ? 1u : 0u); // the cells the reference would have loaded: all but a final one outside the grid
 	return st;
@@ -419,6 +435,7 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 	r.tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
 	r.dx = static_cast<float>(sx) * rx; r.dy = static_cast<float>(sy) * ry; r.dz = static_cast<float>(sz) * rz;
 	r.last_step = 0;
+	r.last_axis = -1;
 	if (DBG) tally.index_loads++; // one per visited cell = the reference's index loads (algorithmic count)
 	// octant of the direction: a zero component never moves, either plane is valid for it
 	const uint32_t oct = (dir.x < 0.f ? 1u : 0u) | (dir.y < 0.f ? 2u : 0u) | (dir.z < 0.f ? 4u : 0u);
@@ -427,7 +444,9 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 }
 
 // voxel.cuh:200-247: the current cell holds a non-empty brick -- read its index word and resolve it.
-template <bool DBG>
+// AXIS: the axis of the last move comes from r.last_axis (trace_k.hip) instead of the packed increment r.last_step.
+// OVERLAY: brick staging layout, see intersect_grid.
+template <bool DBG, bool AXIS = false, bool OVERLAY = false>
 __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const int* campos, RayState& r, HitInfo& info, Tally& tally,
 													 unsigned long long* lds_brick, uint32_t* walk_trips = nullptr) {
 	const int px = cell_x(r.p), py = cell_y(r.p), pz = cell_z(r.p);
@@ -445,7 +464,7 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	brick.q0 = brick.q1 = brick.q2 = brick.q3 = make_uint4(0u, 0u, 0u, 0u);
 	// voxel.cuh:202-206, by select: entry normal and entry distance from the axis of the last move; a ray that starts
 	// inside this cell (no move yet) keeps its normal and enters at distance 0
-	const int axis = move_axis(r.last_step);
+	const int axis = AXIS ? r.last_axis : move_axis(r.last_step);
 	const float new_distance = axis == 0 ? r.tx - r.dx : (axis == 1 ? r.ty - r.dy : (axis == 2 ? r.tz - r.dz : 0.f));
 	r.n = mk(axis == -1 ? r.n.x : (axis == 0 ? -static_cast<float>(sx) : 0.f), axis == -1 ? r.n.y : (axis == 1 ? -static_cast<float>(sy) : 0.f),
 			 axis == -1 ? r.n.z : (axis == 2 ? -static_cast<float>(sz) : 0.f));
@@ -508,7 +527,7 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 #else
 		brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
 #endif
-		if (intersect_grid<8, DBG>(o8, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick, walk_trips)) {
+		if (intersect_grid<8, DBG, OVERLAY>(o8, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick, walk_trips)) {
 			r.distance = new_distance * 8.f + sub_distance + r.tminn;
 			if (DBG) { info.level = 2; info.sub_id = pretest_skip ? (sub | 0x4000) : sub; } // (poison: the pre-test would have dropped a hit)
 			r.hit = true;

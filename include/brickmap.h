@@ -45,6 +45,10 @@ extern "C" {
                                    words 0-3 the first-hit record of the launch's first sample.
                                    For shards with few pixels and many samples, e.g. 1/N row bands of a multi-GPU frame */
 
+#define BM_FLAG_KSLOT 8u        /* run this frame with the K-slot schedule (csrc/trace_k.hip: K paths per lane, path state in LDS):
+                                   same paths, same per-pixel event order, hit records bit-identical to the default schedule's
+                                   (the environment variable BM_SCHEDULE=kslot selects it for every frame of the process) */
+
 typedef struct bm_scene bm_scene; /* Scene + its GPUScene view (Scene.h:7-44), one GPU */
 
 /* camera.h:3-10 -- only the fields the kernels read (launch_kernels:384-385,416). */

@@ -30,9 +30,10 @@
  *
  * Numeric contract: IEEE fp32 + - * / sqrt, no FMA contraction (-ffp-contract=off),
  * float->int by truncation.  sin/cos used for *direction sampling* go through
- * orc_sincos() (double-precision Cody-Waite + fdlibm kernel polynomials, result rounded
- * to float) so that CPU and GPU agree bit-for-bit on ray geometry; the sky model uses
- * the platform libm (expf/powf/acosf), compared with a 1e-4 relative tolerance.
+ * orc_sincos() (fp32 throughout: three-constant Cody-Waite reduction + fixed-order degree-7/8
+ * polynomials, the specification csrc/detmath.h implements independently on the device) so
+ * that CPU and GPU agree bit-for-bit on ray geometry; the sky model uses the platform libm
+ * (expf/powf/acosf), compared with a 1e-4 relative tolerance.
  *
  * Two schedules are provided:
  *   mode A  orc_wavefront_*   : the reference's wavefront loop run sequentially
@@ -560,6 +561,11 @@ static int intersect_grid(v3 origin, v3 direction, v3* normal, float* distance, 
 typedef void (*orc_brick_probe_t)(const float* origin_in_brick, const float* direction, uint32_t index_word, const uint32_t* brick16, int hit, unsigned steps);
 static orc_brick_probe_t orc_brick_probe_fn = 0;
 ORC_API void orc_set_brick_probe(orc_brick_probe_t fn) { orc_brick_probe_fn = fn; }
+/* analysis door (tools/sim): one call per ray of the canonical per-pixel render, in path order, before it is traced
+ * (kind 0 = extend, 1 = shadow); single-threaded renders only */
+typedef void (*orc_ray_probe_t)(unsigned pixel, int sample, int kind, const float* origin, const float* direction);
+static orc_ray_probe_t orc_ray_probe_fn = 0;
+ORC_API void orc_set_ray_probe(orc_ray_probe_t fn) { orc_ray_probe_fn = fn; }
 static int intersect_voxel(orc_world* w, v3 origin, const v3 direction, v3* normal, float* distance, i3 camera_position, orc_hit* hit, orc_counters* cnt, int atomic_requests) { /* :135-261 */
 	float tminn;
 	hit->hit = 0; hit->level = 0; hit->brick_id = -1; hit->sub_id = 0;
@@ -1022,6 +1028,7 @@ static void render_pixel(render_job* job, const cam_basis* cb, const orc_sky_sta
 			/* extend (kernel.cu:226-238) */
 			float distance = VERY_FAR;
 			orc_hit hit;
+			if (orc_ray_probe_fn) orc_ray_probe_fn(p, s, 0, &origin.x, &direction.x);
 			intersect_voxel(w, origin, direction, &normal, &distance, cb->campos, &hit, &job->cnt, job->atomic_requests);
 			job->cnt.extend_rays++;
 			next++;
@@ -1077,6 +1084,7 @@ static void render_pixel(render_job* job, const cam_basis* cb, const orc_sky_sta
 					v3 yn = V3(0, 0, 0);
 					float t = 0.f;
 					orc_hit sh;
+					if (orc_ray_probe_fn) orc_ray_probe_fn(p, s, 1, &shadow_origin.x, &sunSampleDir.x);
 					int occluded = intersect_voxel(w, shadow_origin, sunSampleDir, &yn, &t, cb->campos, &sh, &job->cnt, job->atomic_requests);
 					job->cnt.shadow_rays++;
 					nsh++;

@@ -33,23 +33,49 @@ def gpu_render(bm, torch, scene, cam, params, accum=None, want_dbg=True, also_pl
     """Render through the C-ABI.  With want_dbg the instrumented instantiation trace_paths<true> runs (hit records for the
     oracle comparison); the SAME frame is then rendered again with the production instantiation trace_paths<false> (the
     one bench.py times: no hit records, no counters, twice the occupancy) and must give a bit-identical accumulator --
-    so every case that checks the instrumented kernel against the oracle also pins the benchmarked one."""
+    so every case that checks the instrumented kernel against the oracle also pins the benchmarked one.
+    The frame is rendered twice more with the K-slot schedule (BM_FLAG_KSLOT, csrc/trace_k.hip: instrumented and production
+    instantiation): same accumulator bits, same hit records -- every parity case pins both schedules."""
+    import copy
     rows = bm.local_rows(params)
     if accum is None:
         accum = torch.zeros((rows, params.width, 4), dtype=torch.float32, device="cuda:0")
-    before = accum.clone() if (want_dbg and also_plain) else None
+    check_kslot = os.environ.get("BM_TEST_KSLOT", "1") != "0" and not (params.flags & bm.BM_FLAG_KSLOT)
+    before = accum.clone() if ((want_dbg and also_plain) or check_kslot) else None
     dbg = torch.zeros((rows, params.width, 8), dtype=torch.int32, device="cuda:0") if want_dbg else None
     scene.render(cam, params, accum, debug=dbg)
     torch.cuda.synchronize()
-    if before is not None:
-        import copy
+    a = accum.cpu().numpy()
+    if want_dbg and also_plain:
         plain = copy.copy(params)
         plain.flags = params.flags & ~bm.BM_FLAG_COUNTERS
-        scene.render(cam, plain, before)
+        acc2 = before.clone()
+        scene.render(cam, plain, acc2)
         torch.cuda.synchronize()
-        a, b = accum.cpu().numpy(), before.cpu().numpy()
+        b = acc2.cpu().numpy()
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "trace_paths<false> differs from trace_paths<true>"
-    return accum.cpu().numpy(), (dbg.cpu().numpy().view(np.uint32) if want_dbg else None)
+    if check_kslot:
+        atomic_sum = bool(params.flags & bm.BM_FLAG_SAMPLE_ITEMS)  # samples of a pixel are added with float atomics: order not fixed
+        # (without BM_FLAG_COUNTERS: the scene's traversal counters belong to the caller's own frames; test_kslot_counters pins the K-slot ones)
+        variants = [((params.flags & ~bm.BM_FLAG_COUNTERS) | bm.BM_FLAG_KSLOT, want_dbg)]
+        if want_dbg and also_plain:
+            variants.append(((params.flags & ~bm.BM_FLAG_COUNTERS) | bm.BM_FLAG_KSLOT, False))
+        for flags, with_dbg in variants:
+            kp = copy.copy(params)
+            kp.flags = flags
+            acc_k = before.clone()
+            dbg_k = torch.zeros((rows, params.width, 8), dtype=torch.int32, device="cuda:0") if with_dbg else None
+            scene.render(cam, kp, acc_k, debug=dbg_k)
+            torch.cuda.synchronize()
+            k = acc_k.cpu().numpy()
+            if atomic_sum:
+                np.testing.assert_allclose(k, a, rtol=2e-5, atol=1e-7, err_msg="K-slot schedule: radiance differs")
+                assert np.array_equal(k[..., 3], a[..., 3]), "K-slot schedule: terminated-path counts differ"
+            else:
+                assert np.array_equal(k.view(np.uint32), a.view(np.uint32)), "K-slot schedule: accumulator differs from the default schedule's"
+            if with_dbg:
+                assert np.array_equal(dbg_k.cpu().numpy().view(np.uint32), dbg.cpu().numpy().view(np.uint32)), "K-slot schedule: hit records differ"
+    return a, (dbg.cpu().numpy().view(np.uint32) if want_dbg else None)
 
 
 def cameras(bm, orc, grid, pos=None, h=0.8, v=-0.5, direction=None):
@@ -989,3 +1015,22 @@ def test_frames_overlapping_on_two_streams(bm, orc, torch_cuda, scene256):
     a, b = got.cpu().numpy(), want.cpu().numpy()
     assert np.array_equal(a[..., 3], b[..., 3])  # terminated paths per pixel: exact in any order
     np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=2e-6, atol=1e-9)
+
+
+def test_kslot_counters(bm, torch_cuda, scene256, world256, orc):
+    """The K-slot schedule (BM_FLAG_KSLOT) visits the same cells, tests the same bricks and traces the same rays as the oracle:
+    its traversal counters are the oracle's exactly (and therefore the default schedule's)."""
+    torch = torch_cuda
+    W, H = 160, 120
+    cam, ocam = cameras(bm, orc, 256)
+    _, _, ocnt, _ = world256.render(ocam, orc.make_frame(W, H, spp=2, max_bounces=3))
+    scene256.counters_reset()
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    scene256.render(cam, bm.FrameParams(W, H, spp=2, max_bounces=3, flags=bm.BM_FLAG_COUNTERS | bm.BM_FLAG_KSLOT), acc)
+    torch.cuda.synchronize()
+    got = scene256.counters()
+    for name in ("index_loads", "brick_tests", "byte_tests", "voxel_steps", "extend_rays", "shadow_rays", "paths"):
+        assert got[name] == ocnt[name], (name, got[name], ocnt[name])
+    st = scene256.sched_stats()
+    assert st["waves"] > 0 and st["jump_runs"] > 0 and st["candidate_runs"] > 0 and st["shade_runs"] > 0
+    scene256.counters_reset()
