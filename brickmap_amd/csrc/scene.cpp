@@ -13,9 +13,6 @@
 
 #include "kernels.h"
 
-#ifndef BM_FIELD_BLOCKED
-#define BM_FIELD_BLOCKED 0
-#endif
 
 namespace bm {
 
@@ -471,29 +468,6 @@ int Scene::allocate_device() {
 		std::vector<uint8_t> field;
 		world.build_cube_field(field, 8);
 		const int cfx = d.cells + 2;
-#if BM_FIELD_BLOCKED
-		{ // experiment: 4x4x4-cell blocks of 64 bytes (one L2 sector) instead of rows; traverse.h field_lookup has the addressing
-			const int nbx = d.cells / 4 + 2, nbz = d.cells_height / 4 + 2;
-			const size_t bplane = static_cast<size_t>(nbx) * nbx * nbz * 64, rplane = field.size() / 8;
-			std::vector<uint8_t> blocked(bplane * 8, 255);
-			for (int o = 0; o < 8; ++o)
-				for (int z = 0; z < d.cells_height + 2; ++z)
-					for (int y = 0; y < cfx; ++y)
-						for (int x = 0; x < cfx; ++x) {
-							const int fx = x + 15, fy = y + 15, fz = z + 15; // the packed cell's biased fields
-							const size_t b = (static_cast<size_t>((fz >> 2) - 3) * nbx + ((fy >> 2) - 3)) * nbx + ((fx >> 2) - 3);
-							blocked[bplane * o + b * 64 + (fz & 3) * 16 + (fy & 3) * 4 + (fx & 3)] = field[rplane * o + (static_cast<size_t>(z) * cfx + y) * cfx + x];
-						}
-			field.swap(blocked);
-			BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cube_field_), field.size()));
-			BM_HIP(hipMemcpy(d_cube_field_, field.data(), field.size(), hipMemcpyHostToDevice));
-			view_.cf_x = nbx;
-			view_.cf_xy = nbx * nbx;
-			view_.cf_plane = static_cast<uint32_t>(bplane);
-			view_.cube_field = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(d_cube_field_) - static_cast<uintptr_t>(3) * 64 * (1 + nbx + nbx * nbx));
-			cube_field_bytes_ = field.size();
-		}
-#else
 		BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cube_field_), field.size()));
 		BM_HIP(hipMemcpy(d_cube_field_, field.data(), field.size(), hipMemcpyHostToDevice));
 		view_.cf_x = cfx;
@@ -501,7 +475,6 @@ int Scene::allocate_device() {
 		view_.cf_plane = static_cast<uint32_t>(field.size() / 8);
 		view_.cube_field = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(d_cube_field_) - static_cast<uintptr_t>(15) * (1 + cfx + cfx * cfx));
 		cube_field_bytes_ = field.size();
-#endif
 	}
 	view_.cells = d.cells;
 	view_.cells_height = d.cells_height;

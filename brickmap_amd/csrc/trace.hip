@@ -58,12 +58,6 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_PRIO_C
 #define BM_PRIO_C 0
 #endif
-#ifndef BM_XCD_TILES
-#define BM_XCD_TILES 0 // > 0: XCD-aware hand-out in super-tiles of this many 16x16-pixel tiles per side (see the refill code)
-#endif
-#ifndef BM_XCD_HWID
-#define BM_XCD_HWID 0
-#endif
 #ifndef BM_WORK_COUNTERS
 #define BM_WORK_COUNTERS 8
 #endif
@@ -81,9 +75,6 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #endif
 #ifndef BM_STEPS_PER_ROUND
 #define BM_STEPS_PER_ROUND 4
-#endif
-#ifndef BM_B_STEP
-#define BM_B_STEP 0
 #endif
 #ifndef BM_REFILL_MIN
 #define BM_REFILL_MIN 16
@@ -145,14 +136,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	constexpr uint32_t kCounters = BM_WORK_COUNTERS, kCounterStride = 32; // one 128-byte line per counter
 	// (the wave index is the same in all 64 lanes; saying so keeps everything derived from it -- the counter in use, `work_left`,
 	// the loop's exit conditions -- in scalar registers and the scheduler loop's branches scalar)
-#if BM_XCD_TILES && BM_XCD_HWID
-	// the XCD this wave runs on, from the hardware (HW_REG_XCC_ID = 20, bits 3:0)
-	int my_counter = static_cast<int>(static_cast<uint32_t>(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11))) % kCounters);
-#elif BM_XCD_TILES
-	int my_counter = static_cast<int>(blockIdx.x % kCounters); // the workgroup's XCD (round-robin dispatch over the 8 XCDs)
-#else
 	int my_counter = static_cast<int>((blockIdx.x * 4u + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)))) % kCounters);
-#endif
 	int counters_done = 0;
 	// hang guard only (NaN directions): no wave needs more scheduler rounds than this
 	const long long round_budget = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fc.spp) + 1) * (fc.max_bounces + 2) *
@@ -187,22 +171,10 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			uint32_t base = 0;
 			if (lane == 0) base = atomicAdd(work_counter + my_counter * kCounterStride, static_cast<uint32_t>(want));
 			base = __builtin_amdgcn_readfirstlane(base);
-#if BM_XCD_TILES
-			// XCD-aware hand-out: the image is cut into super-tiles of BM_XCD_TILES x BM_XCD_TILES tiles (16x16 pixels each), super-tile
-			// st belongs to counter st % kCounters, and a wave starts on the counter of ITS XCD (workgroups go round-robin over the
-			// 8 XCDs, so blockIdx % 8 names the L2): the rays of neighbouring pixels -- which read the same field rows, index words
-			// and bricks -- are traced behind ONE L2 instead of all eight.  Super-tiles are small enough (128 x 128 pixels) that
-			// every XCD gets its share of sky and terrain; a wave whose counter is used up helps the next one.
-			const uint32_t st_x = (static_cast<uint32_t>(fc.tiles_x) + BM_XCD_TILES - 1u) / BM_XCD_TILES, st_y = (static_cast<uint32_t>(fc.tiles_y) + BM_XCD_TILES - 1u) / BM_XCD_TILES;
-			const uint32_t total_st = st_x * st_y;
-			const uint32_t my_st = total_st > static_cast<uint32_t>(my_counter) ? (total_st - static_cast<uint32_t>(my_counter) + kCounters - 1u) / kCounters : 0u;
-			const uint32_t my_tickets = my_st * (BM_XCD_TILES * BM_XCD_TILES * 16u) * items_per_chunk;
-#else
 			const uint32_t total_groups = (total_chunks + 3u) >> 2;
 			const uint32_t my_groups = total_groups > static_cast<uint32_t>(my_counter)
 										   ? (total_groups - static_cast<uint32_t>(my_counter) + kCounters - 1u) / kCounters : 0u;
 			const uint32_t my_tickets = my_groups * 4u * items_per_chunk; // consecutive tickets = the samples of one chunk
-#endif
 			const uint32_t counter_now = static_cast<uint32_t>(my_counter);
 			if (base + want >= my_tickets) { // this counter is used up: move to the next one (helping out), or finish
 				my_counter = (my_counter + 1) % static_cast<int>(kCounters);
@@ -213,20 +185,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				const uint32_t item = base + static_cast<uint32_t>(rank / BM_ITEM_LANES);
 				const uint32_t ticket = item / items_per_chunk, item_sub = item - ticket * items_per_chunk;
 				const uint32_t item_sample = item_sub / kParts, part = item_sub % kParts; // (kParts == 1: part 0)
-#if BM_XCD_TILES
-				constexpr uint32_t kStChunks = BM_XCD_TILES * BM_XCD_TILES * 16u;
-				const uint32_t st = (ticket / kStChunks) * kCounters + counter_now, in_st = ticket % kStChunks;
-				const uint32_t tw = in_st >> 4, k = in_st & 15u;
-				const int tile_x = static_cast<int>((st % st_x) * BM_XCD_TILES + tw % BM_XCD_TILES);
-				const int tile_y = static_cast<int>((st / st_x) * BM_XCD_TILES + tw / BM_XCD_TILES);
-				if (item < my_tickets && tile_x < fc.tiles_x && tile_y < fc.tiles_y) {
-#else
 				const uint32_t chunk = ((ticket >> 2) * kCounters + counter_now) * 4u + (ticket & 3u);
 				if (item < my_tickets && chunk < total_chunks) {
 					const uint32_t tile = chunk >> 4, k = chunk & 15u;
 					const int tile_x = static_cast<int>(tile % static_cast<uint32_t>(fc.tiles_x));
 					const int tile_y = static_cast<int>(tile / static_cast<uint32_t>(fc.tiles_x));
-#endif
 					const int cx = static_cast<int>((k & 1u) | ((k >> 1) & 2u)), cy = static_cast<int>(((k >> 1) & 1u) | ((k >> 2) & 2u));
 					const uint32_t q = part * BM_ITEM_LANES + (static_cast<uint32_t>(rank) % BM_ITEM_LANES); // pixel of the 4x4 chunk
 					const int x = tile_x * 16 + cx * 4 + static_cast<int>(q & 3u);
@@ -262,10 +225,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		const int quorum = (live * BM_QUORUM_NUM + BM_QUORUM_DIV - 1) / BM_QUORUM_DIV;
 		const int quorum_shade = (live * BM_QUORUM_SHADE_NUM + BM_QUORUM_SHADE_DIV - 1) / BM_QUORUM_SHADE_DIV;
 		int phase; // 0 = A (DDA moves), 1 = B (candidates), 2 = C (shade / generate), 3 = D (connect)
-#ifdef BM_ARGMAX_WB
-		if (true) { const int vA = nA * 4, vB = nB * BM_ARGMAX_WB, vC = nC * BM_ARGMAX_WC; phase = (vC >= vA && vC >= vB) ? 2 : (vB >= vA ? 1 : 0); }
-		else
-#endif
 		if (nC >= quorum_shade) phase = 2;
 		else if (nB >= quorum) phase = 1;
 		else if (nA > 0) phase = 0;
@@ -446,11 +405,6 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 #else
 			if (state == ST_CAND) {
 				int st = process_candidate<DBG>(sc, fc.campos, r, info, tally, lds_brick);
-#endif
-#if BM_B_STEP
-				// a ray that passed through the brick makes its move out of the cell right here: it is the only thing it can do
-				// next, and near a surface the next cell is often a candidate again
-				if (st == ST_OUTER) st = field_step<DBG>(sc, r, tally);
 #endif
 				state = (st == ST_NEED && shadow) ? ST_CONN : st;
 			}

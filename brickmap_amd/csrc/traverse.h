@@ -10,19 +10,6 @@
 #include "device_types.h"
 #include "jump.h"
 
-#ifndef BM_FIELD_BLOCKED
-#define BM_FIELD_BLOCKED 0 // 1: cube field in 4x4x4-cell blocks of 64 bytes (scene.cpp lays it out accordingly)
-#endif
-#ifndef BM_LOD_PRETEST
-#define BM_LOD_PRETEST 0 // 1: candidates are pre-tested against the index word's 2^3 LoD byte before their brick is fetched (process_candidate)
-#endif
-#ifndef BM_NT_BRICKS
-#define BM_NT_BRICKS 0 // 1: the 64-byte brick is fetched with non-temporal loads (it is used once; keeps field lines in the L2)
-#endif
-#ifndef BM_CMP3
-#define BM_CMP3 0 // 1: the walks pick their axis with three float compares instead of the reference's four (see intersect_grid)
-#endif
-
 namespace bm {
 
 namespace {
@@ -149,14 +136,8 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 	int guard = 3 * N + 1;
 	for (; !solid && inside && guard > 0; --guard) {
 		// select-style move (voxel.cuh:122-130); `t += mask ? delta : 0` is `tmax += mask * tdelta` for finite deltas
-#if BM_CMP3
-		const bool xy = tx < ty; // for ordered operands ty <= tx is !(tx < ty): three compares instead of four (a NaN tmax makes no
-		const bool mx = xy && tx < tz; // sense in the reference either: its loop would never move, voxel.cuh:249-258)
-		const bool my = !xy && ty < tz;
-#else
 		const bool mx = tx < ty && tx < tz;
 		const bool my = ty <= tx && ty < tz; // mx implies !my
-#endif
 		const bool mz = !(mx || my);
 		last = mx ? step_x : (my ? step_y : step_z);
 		cell += static_cast<uint32_t>(last);
@@ -230,25 +211,14 @@ __device__ __forceinline__ int move_axis(int last_step) {
 // moved n cells, so the walk may take up to that many steps without looking at the grid: field_jump does it in one go,
 // landing on the bit-exact tmax values of the reference's cell-by-cell walk (jump.h); cubes too small to pay for a jump
 // are crossed by single steps.  One byte per visited cell replaces the 16-byte block record + bit test of the mask walk.
-#ifndef BM_JUMP_BINADES
-#define BM_JUMP_BINADES 1 // binades a jump may cross inside one pass (1: a jump stops at the end of its binade and looks the cube field up again)
-#endif
 #ifndef BM_JUMP_MIN
 #define BM_JUMP_MIN 4 // smallest cube edge worth a jump (a jump costs about four single steps)
 #endif
 constexpr uint32_t kCubeNoJump = 0x100u; // RayState::cube flag: tmax is outside the range of jump.h, take single moves
 __device__ __forceinline__ int field_lookup(const DeviceScene& sc, RayState& r) {
-#if BM_FIELD_BLOCKED
-	// experiment: the field in 4x4x4-cell blocks of 64 bytes.  Block coordinate = (field >> 2) - 3 (the -3 folded into
-	// sc.cube_field), position inside the block = the low two bits of every field.
-	const uint32_t xb = (r.p >> 2) & 0x1FFu, yb = (r.p >> 13) & 0x1FFu, zb = r.p >> 24;
-	const uint32_t within = (r.p & 3u) | ((r.p >> 9) & 0xCu) | ((r.p >> 18) & 0x30u);
-	const uint32_t idx = ((__umul24(zb, static_cast<uint32_t>(sc.cf_xy)) + (__umul24(yb, static_cast<uint32_t>(sc.cf_x)) + xb)) << 6) + within + r.field_off;
-#else
 	const uint32_t fx = r.p & 0x7FFu, fy = (r.p >> 11) & 0x7FFu, fz = r.p >> 22;
 	// bordered cell coordinate = field - 15 (16-cell bias, one border cell): the three "- 15" are folded into sc.cube_field
 	const uint32_t idx = __umul24(fz, static_cast<uint32_t>(sc.cf_xy)) + (__umul24(fy, static_cast<uint32_t>(sc.cf_x)) + fx) + r.field_off;
-#endif
 	const uint32_t v = sc.cube_field[idx];
 	const float m = fminf(fminf(r.tx, r.ty), r.tz);
 	// select-style, no short-circuit: a branchy version costs its full instruction count in a divergent wave anyway
@@ -266,14 +236,8 @@ __device__ __forceinline__ int field_lookup(const DeviceScene& sc, RayState& r) 
 template <bool DBG>
 __device__ __forceinline__ int field_step(const DeviceScene& sc, RayState& r, Tally& tally) {
 	const float tx = r.tx, ty = r.ty, tz = r.tz;
-#if BM_CMP3
-	const bool xy = tx < ty; // see intersect_grid: three compares instead of four
-	const bool mx = xy && tx < tz;
-	const bool my = !xy && ty < tz;
-#else
 	const bool mx = tx < ty && tx < tz;
 	const bool my = ty <= tx && ty < tz; // mx implies !my
-#endif
 	const bool mz = !(mx || my);
 	const int step_x = r.sx, step_y = r.stepy, step_z = r.stepz; // scalar copies: selects between struct members pin the struct in scratch
 	const int step = mx ? step_x : (my ? step_y : step_z);
@@ -303,30 +267,7 @@ __device__ __forceinline__ int field_jump(const DeviceScene& sc, RayState& r, Ta
 	const float ix = DIR ? fabsf(r.d.x) : (dx > 0.f ? __builtin_amdgcn_rcpf(dx) : 0.f);
 	const float iy = DIR ? fabsf(r.d.y) : (dy > 0.f ? __builtin_amdgcn_rcpf(dy) : 0.f);
 	const float iz = DIR ? fabsf(r.d.z) : (dz > 0.f ? __builtin_amdgcn_rcpf(dz) : 0.f);
-#if BM_JUMP_BINADES > 1
-	// A jump that stops at a binade end is still inside its cube: it goes on in the next binade with what is left of the
-	// budget on every axis (no new cube-field byte is needed for that), up to BM_JUMP_BINADES binades per pass; the trip count
-	// is the wave's (ballot), lanes that have left their cube wait.  After a binade stop the state is exactly the reference's
-	// (the last addition of every axis is a real fp32 addition, jump.h), so the continuation is a fresh jump.
-	{
-		uint32_t bx = n ? n : 1u, by = bx, bz = bx;
-		cx = cy = cz = 0u;
-		bool going = true;
-#pragma unroll 1
-		for (int it = 0; it < BM_JUMP_BINADES; ++it) {
-			if (going) {
-				uint32_t ax_, ay_, az_;
-				const bool exited = dda_jump3(tx, ty, tz, dx, dy, dz, ix, iy, iz, bx, by, bz, ax_, ay_, az_, axis);
-				cx += ax_; cy += ay_; cz += az_;
-				bx -= ax_; by -= ay_; bz -= az_; // a binade stop leaves every count below its budget: all three stay >= 1
-				going = !exited && jump_possible(tx, ty, tz);
-			}
-			if (__ballot(going) == 0ull) break;
-		}
-	}
-#else
 	dda_jump(tx, ty, tz, dx, dy, dz, ix, iy, iz, n, cx, cy, cz, axis);
-#endif
 	r.tx = tx; r.ty = ty; r.tz = tz;
 	// all three products fit 24-bit signed multiplies: counts <= 255, increments +-1 / +-2^11 / +-2^22
 	r.p += static_cast<uint32_t>(__mul24(static_cast<int>(cx), step_x) + __mul24(static_cast<int>(cy), step_y) + __mul24(static_cast<int>(cz), step_z));
@@ -491,48 +432,13 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 		if (DBG) tally.brick_tests++;
 		int sub = 0;
 		const f3 o8 = (r.o + r.d * new_distance) * 8.f - r.n * kEpsilon;
-		bool walk = true, pretest_skip = false;
-#if BM_LOD_PRETEST
-		// Conservative pre-test against the 2^3 LoD byte of the index word (Scene.cpp:95: bit xb + 2 yb + 4 zb = "the 4^3 sub-block holds
-		// a voxel"): the exact walk only visits voxels within ~1e-5 voxel of the chord from the entry point to the point where the
-		// ray leaves the brick, so if no occupied sub-block overlaps the chord's bounding box grown by 0.01 voxel, the walk cannot
-		// find a voxel and the 64-byte brick need not be fetched.  Only when the walk's start voxel lies inside the brick (a start
-		// cell just outside wraps around in the reference, `pos % 8`, voxel.cuh:96-101); NaNs select every sub-block.  The
-		// instrumented kernel always walks (its counters are the reference's) and poisons the hit record if a skipped brick was hit.
-		{
-			const float pox = o8.x - static_cast<float>(px * 8), poy = o8.y - static_cast<float>(py * 8), poz = o8.z - static_cast<float>(pz * 8);
-			const bool in = pox >= 0.f && pox < 8.f && poy >= 0.f && poy < 8.f && poz >= 0.f && poz < 8.f;
-			const float ex = r.d.x > 0.f ? (8.f - pox) * r.dx : (r.d.x < 0.f ? pox * r.dx : 1e30f);
-			const float ey = r.d.y > 0.f ? (8.f - poy) * r.dy : (r.d.y < 0.f ? poy * r.dy : 1e30f);
-			const float ez = r.d.z > 0.f ? (8.f - poz) * r.dz : (r.d.z < 0.f ? poz * r.dz : 1e30f);
-			const float te = fmaxf(fminf(fminf(ex, ey), ez), 0.f);
-			const float qx = pox + r.d.x * te, qy = poy + r.d.y * te, qz = poz + r.d.z * te;
-			const uint32_t xm = (!(fminf(pox, qx) - 0.01f >= 4.f) ? 0x55u : 0u) | (!(fmaxf(pox, qx) + 0.01f < 4.f) ? 0xAAu : 0u);
-			const uint32_t ym = (!(fminf(poy, qy) - 0.01f >= 4.f) ? 0x33u : 0u) | (!(fmaxf(poy, qy) + 0.01f < 4.f) ? 0xCCu : 0u);
-			const uint32_t zm = (!(fminf(poz, qz) - 0.01f >= 4.f) ? 0x0Fu : 0u) | (!(fmaxf(poz, qz) + 0.01f < 4.f) ? 0xF0u : 0u);
-			pretest_skip = in && ((((index & kLodBits) >> 12) & xm & ym & zm) == 0u);
-			if (!DBG) walk = !pretest_skip;
-		}
-#endif
-		if (walk) {
 		const uint4* bq = reinterpret_cast<const uint4*>(sc.brick_arena + (static_cast<size_t>(pool + (index & kIndexBits)) << 4));
-#if BM_NT_BRICKS
-		{
-			typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-			const v4u* nq = reinterpret_cast<const v4u*>(bq);
-			const v4u a = __builtin_nontemporal_load(nq), b = __builtin_nontemporal_load(nq + 1), c = __builtin_nontemporal_load(nq + 2), d = __builtin_nontemporal_load(nq + 3);
-			brick.q0 = make_uint4(a.x, a.y, a.z, a.w); brick.q1 = make_uint4(b.x, b.y, b.z, b.w);
-			brick.q2 = make_uint4(c.x, c.y, c.z, c.w); brick.q3 = make_uint4(d.x, d.y, d.z, d.w);
-		}
-#else
 		brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
-#endif
 		if (intersect_grid<8, DBG, OVERLAY>(o8, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick, walk_trips)) {
 			r.distance = new_distance * 8.f + sub_distance + r.tminn;
-			if (DBG) { info.level = 2; info.sub_id = pretest_skip ? (sub | 0x4000) : sub; } // (poison: the pre-test would have dropped a hit)
+			if (DBG) { info.level = 2; info.sub_id = sub; }
 			r.hit = true;
 			return ST_NEED;
-		}
 		}
 	} else if (index & kUnloadedBit) {
 		// brick-request protocol (voxel.cuh:228-245): 32-bit atomics on the index word and the ring counter
