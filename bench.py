@@ -43,10 +43,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # what bounds trace_paths on each workload (profiles/r03_pmc_summary_<workload>.json, profiles/r03_fetch_calibration.txt)
 LIMITER = {
-    "config1": "launch latency (a 256x256 frame is 65 k paths: less than one wave-load per SIMD)",
     "config2": "VALU issue: the vector pipes are busy for >= 85 % of the launch with ~20 of 64 lanes active per instruction; the scene (93 MiB) stays in L2 / Infinity Cache",
     "config3": "VALU issue, with 0.6 G L2 sector misses per launch (TCC hit 61 %)",
-    "config4": "VALU issue, with 0.6 G L2 sector misses per launch (TCC hit 61 %)",
     "config5": "two limits at once: 41.5 G single-sector (64 B) read requests/s = 0.86 of the 48 G/s the fabric sustains for random sectors (3.1 TB/s, not the 8 TB/s byte peak), and VALU issue (vector pipes full at ~18 of 64 lanes per instruction)",
 }
 PROFILE_ROUND = "r03"  # profiles/<round>_pmc_summary*.json is where roofline.traffic comes from
@@ -368,6 +366,37 @@ def main():
             torch.cuda.synchronize()
             same_job = {"error": repr(e)}
 
+    # ---- what the N > 1 lines should come out at, measured on THIS GPU (N = 1 / config 2 line only, untimed extra): rank 0's
+    # 1/N shard of the same 8-spp job (interleaved 16-row bands, (chunk, sample) items), N = 2 / 4 / 8, consecutive steps on one
+    # stream.  predicted_speedup = unsharded job time / shard time: the kernels alone, before the gather (4.1 MB per peer per
+    # step at N = 8, issued behind the frame and overlapped with the next one).  The first real SCALE run is checked against it.
+    shard_pred = None
+    if not multi and args.workload == "config2" and not streaming and not args.no_extras and same_job is not None and "ms_per_step" in same_job:
+        try:
+            shard_pred = {"job": same_job["workload"], "unsharded_ms_per_step": same_job["ms_per_step"], "shard_kernel_ms": {}, "shard_ms_per_step": {},
+                          "predicted_speedup": {}, "note": "rank 0's shard of the job on this GPU, one stream, no gather: value(N) / value(1 GPU, same job) "
+                          "should come out near predicted_speedup[N]"}
+            for n_ranks in (2, 4, 8):
+                st = bm.State(W, H, device=local_rank, band_rows=band, shard_rank=0, shard_count=n_ranks)
+                ps = lambda i: bm.FrameParams(W, H, spp=job_spp, sample_base=7000 + i * job_spp, max_bounces=max_bounces, flags=bm.BM_FLAG_SAMPLE_ITEMS,
+                                              band_rows=band, shard_rank=0, shard_count=n_ranks)
+                ns = 6
+                for i in range(2):
+                    scene.render(cam, ps(i), st.blit_buffer)
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                for i in range(ns):
+                    scene.render(cam, ps(2 + i), st.blit_buffer)
+                torch.cuda.synchronize()
+                ss = (time.perf_counter() - ts) / ns * 1e3
+                shard_pred["shard_ms_per_step"][str(n_ranks)] = round(ss, 4)
+                shard_pred["shard_kernel_ms"][str(n_ranks)] = round(float(np.mean(scene.render_times(ns))), 4)
+                shard_pred["predicted_speedup"][str(n_ranks)] = round(same_job["ms_per_step"] / ss, 3)
+                del st
+        except Exception as e:  # noqa: BLE001 -- an extra: must not cost the headline measurement
+            torch.cuda.synchronize()
+            shard_pred = {"error": repr(e)}
+
     if multi:
         dist.barrier()  # rank 0's untimed extras are done: every rank leaves the process group together
     if rank != 0:
@@ -411,7 +440,7 @@ def main():
             # kernel itself reads far less (one cube-field byte per STOP of the walk, index words only at candidates: see
             # `traffic`, from the PMC counters); `limiter` names what actually bounds it on this workload.
             "achieved_is": "reference-equivalent (algorithmic) bytes per launch / kernel duration",
-            "limiter": LIMITER.get(args.workload, LIMITER["config2"]),
+            **limiter_of(args.workload),
             "achieved": round(achieved_gbs, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -439,6 +468,8 @@ def main():
         out["verified_against_single_gpu"] = verified
     if same_job is not None:
         out["same_job_single_gpu" if multi else "multi_gpu_job_on_one_gpu"] = same_job
+    if shard_pred is not None:
+        out["multi_gpu_prediction"] = shard_pred
     if not multi and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, H, max_bounces, G, cam)
     print(json.dumps(out), flush=True)
@@ -593,6 +624,16 @@ def cpu_baseline(W, H, max_bounces, G, cam):
         "one_thread": {"value": round(nominal1 / secs1 / 1e6, 4), "unit": "Mrays/s",
                        "sample": f"every 8th 8-row band of one frame ({nominal1} nominal rays, {cnt1['extend_rays'] + cnt1['shadow_rays']} actual) in {secs1:.2f} s"},
     }
+
+
+def limiter_of(workload):
+    """{"limiter": what bounds the kernel on this workload, "limiter_source": the committed counter passes the statement rests on}.
+    The statement is about the DEFAULT build and schedule as profiled in `limiter_source` (not re-derived by this run); it is
+    omitted when no PMC summary of the workload is committed (config 1, config 4: config 3's kernel on another frame size)."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_summary_{workload}.json")
+    if workload not in LIMITER or not os.path.exists(path) or os.environ.get("BM_SCHEDULE"):
+        return {"limiter": None, "limiter_source": None}
+    return {"limiter": LIMITER[workload], "limiter_source": f"profiles/{os.path.basename(path)} + DESIGN.md 5 (default build, default schedule)"}
 
 
 def pmc_traffic(workload):

@@ -119,6 +119,15 @@ SIGNATURES = {
     "bm_wavefront_counters_read": (_i, [_vp, _i, C.POINTER(bm_counters)]),
     "bm_wavefront_counters_reset": (_i, [_vp]),
     "bm_wavefront_sched_stats_read": (_i, [_vp, _i, C.POINTER(C.c_uint64)]),
+    "bm_comm_unique_id": (_i, [_vp]),
+    "bm_comm_create": (_i, [_i, _i, _i, _vp, C.POINTER(_vp)]),
+    "bm_comm_destroy": (None, [_vp]),
+    "bm_comm_info": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bm_gather_frame": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "bm_reduce_frame": (_i, [_vp, _vp, _vp, C.c_int64, _i, _vp]),
+    "bm_comm_barrier": (_i, [_vp, _vp]),
+    "bm_comm_selftest": (_i, [_vp, _vp]),
+    "bm_debug_assemble_frame": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "bm_debug_sincos": (_i, [_i, _i, _vp, _vp, _vp]),
     "bm_debug_sky": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp]),
 }

@@ -18,6 +18,7 @@ void launch_trace_k(const DeviceScene& sc, const FrameConstants& fc, const Frame
 void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const uint32_t* indices_queue, uint32_t* arena, uint32_t count,
 				   hipStream_t stream);
 void launch_pool_moves(const PoolMove* moves, uint32_t count, uint32_t* arena, uint32_t* pool_base, hipStream_t stream);
+void launch_snapshot_ring(const int* queue, const uint32_t* count, int* host_positions, uint32_t* host_count, uint32_t capacity, hipStream_t stream);
 void launch_resolve(const float* accum, float* out, long long n, hipStream_t stream);
 void launch_debug_sincos(int n, const float* x, float* s, float* c, hipStream_t stream);
 void launch_debug_sky(const FrameConstants& fc, int n, const float* v, float* sun, float* sky, float* sunsky, hipStream_t stream);

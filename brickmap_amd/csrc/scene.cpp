@@ -13,7 +13,6 @@
 
 #include "kernels.h"
 
-
 namespace bm {
 
 // ---------------------------------------------------------------- errors
@@ -280,6 +279,8 @@ void Scene::free_device() {
 	arena_close();
 	if (d_cube_field_) hipFree(d_cube_field_);
 	d_cube_field_ = nullptr;
+	if (d_coarse_field_) hipFree(d_coarse_field_);
+	d_coarse_field_ = nullptr;
 	d_index_grid_ = d_arena_ = d_pool_base_ = nullptr;
 	arena_capacity_ = arena_top_ = pool_bricks_ = 0;
 	on_device_ = false;
@@ -323,12 +324,18 @@ int Scene::arena_open(uint64_t max_bricks) {
 }
 
 int Scene::arena_unmap_all() {
-	for (const ArenaChunk& c : arena_chunks_) {
-		BM_HIP(hipMemUnmap(reinterpret_cast<char*>(d_arena_) + c.offset, c.bytes));
-		BM_HIP(hipMemRelease(c.handle));
+	// every chunk is taken off the list as it is processed (a chunk that failed to unmap must not be unmapped and released a
+	// second time by a later call); the first error is reported after all of them have been tried
+	hipError_t first = hipSuccess;
+	const char* what = "";
+	while (!arena_chunks_.empty()) {
+		const ArenaChunk c = arena_chunks_.back();
+		arena_chunks_.pop_back();
+		if (hipError_t e = hipMemUnmap(reinterpret_cast<char*>(d_arena_) + c.offset, c.bytes); e != hipSuccess && first == hipSuccess) { first = e; what = "hipMemUnmap"; }
+		if (hipError_t e = hipMemRelease(c.handle); e != hipSuccess && first == hipSuccess) { first = e; what = "hipMemRelease"; }
 	}
-	arena_chunks_.clear();
 	arena_capacity_ = 0;
+	if (first != hipSuccess) return hip_fail(first, what, __FILE__, __LINE__);
 	return 0;
 }
 
@@ -336,8 +343,9 @@ void Scene::arena_close() {
 	if (arena_virtual_) {
 		// unlike hipFree, unmapping does not wait for work that still uses the range
 		if (!arena_chunks_.empty()) (void)hipDeviceSynchronize();
-		(void)arena_unmap_all();
-		if (d_arena_) (void)hipMemAddressFree(d_arena_, arena_va_bytes_);
+		const int unmap_error = arena_unmap_all();
+		// (a range that may still hold a mapping is not handed back: leaking address space is harmless, freeing a mapped range is not)
+		if (d_arena_ && unmap_error == 0) (void)hipMemAddressFree(d_arena_, arena_va_bytes_);
 	} else if (d_arena_) {
 		(void)hipFree(d_arena_);
 	}
@@ -359,16 +367,21 @@ int Scene::arena_reserve(uint64_t bricks, bool exact) {
 		const size_t gran = arena_granularity_;
 		auto round_up = [gran](uint64_t b) { return (b + gran - 1) / gran * gran; };
 		uint64_t want_bytes;
+		bool remapping_empty_arena = false;
+		// (when the arena was unmapped for an exact re-size, any failure below marks the scene failed: frames are refused until
+		// bm_scene_reset_residency / bm_scene_preload_all succeeds -- the device index words may still carry loaded bits)
+		auto fail = [&](int code) { if (remapping_empty_arena) failed_ = true; return code; };
 		if (exact && arena_top_ == 0) {
 			if (!arena_chunks_.empty()) BM_HIP(hipDeviceSynchronize()); // (callers have synchronised already; unmapping itself does not wait)
-			if (int e = arena_unmap_all()) return e;
+			if (int e = arena_unmap_all()) { failed_ = true; return e; }
+			remapping_empty_arena = true; // from here on a failure leaves view_.brick_arena pointing at an unmapped range
 			want_bytes = round_up(std::max<uint64_t>(bricks, 1ull << 16) * sizeof(Brick));
 		} else {
 			want_bytes = round_up(std::max<uint64_t>(arena_capacity_, 1ull << 16) * sizeof(Brick)); // 4 MiB to start with
 			while (want_bytes < bricks * sizeof(Brick)) want_bytes *= 2;
 		}
 		if (want_bytes > arena_va_bytes_) want_bytes = arena_va_bytes_;
-		if (want_bytes < bricks * sizeof(Brick)) { set_error("brick arena: reserved address range exhausted"); return BM_ESTATE; }
+		if (want_bytes < bricks * sizeof(Brick)) { set_error("brick arena: reserved address range exhausted"); return fail(BM_ESTATE); }
 		const size_t have = static_cast<size_t>(arena_capacity_) * sizeof(Brick);
 		if (want_bytes > have) {
 			hipMemAllocationProp prop{};
@@ -378,9 +391,9 @@ int Scene::arena_reserve(uint64_t bricks, bool exact) {
 			ArenaChunk c{};
 			c.offset = have;
 			c.bytes = want_bytes - have;
-			BM_HIP(hipMemCreate(&c.handle, c.bytes, &prop, 0));
+			if (hipError_t e = hipMemCreate(&c.handle, c.bytes, &prop, 0); e != hipSuccess) return fail(hip_fail(e, "hipMemCreate", __FILE__, __LINE__));
 			char* at = reinterpret_cast<char*>(d_arena_) + c.offset;
-			if (hipError_t e = hipMemMap(at, c.bytes, 0, c.handle, 0); e != hipSuccess) { (void)hipMemRelease(c.handle); return hip_fail(e, "hipMemMap", __FILE__, __LINE__); }
+			if (hipError_t e = hipMemMap(at, c.bytes, 0, c.handle, 0); e != hipSuccess) { (void)hipMemRelease(c.handle); return fail(hip_fail(e, "hipMemMap", __FILE__, __LINE__)); }
 			hipMemAccessDesc access{};
 			access.location = prop.location;
 			access.flags = hipMemAccessFlagsProtReadWrite;
@@ -389,7 +402,7 @@ int Scene::arena_reserve(uint64_t bricks, bool exact) {
 			// (tools/ubench/vmm_probe2.hip: 33 of 144 growths; 0 of 144 this way, with kernels in flight over the range)
 			if (hipError_t e = hipMemSetAccess(d_arena_, want_bytes, &access, 1); e != hipSuccess) {
 				(void)hipMemUnmap(at, c.bytes); (void)hipMemRelease(c.handle);
-				return hip_fail(e, "hipMemSetAccess", __FILE__, __LINE__);
+				return fail(hip_fail(e, "hipMemSetAccess", __FILE__, __LINE__));
 			}
 			arena_chunks_.push_back(c);
 			if (arena_capacity_ > 0) arena_growths_++;
@@ -475,6 +488,26 @@ int Scene::allocate_device() {
 		view_.cf_plane = static_cast<uint32_t>(field.size() / 8);
 		view_.cube_field = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(d_cube_field_) - static_cast<uintptr_t>(15) * (1 + cfx + cfx * cfx));
 		cube_field_bytes_ = field.size();
+		// Coarse level (one byte per 4x4x4 cells and octant, 1/64 of the fine field): for worlds whose fine field cannot stay in
+		// the caches -- config 5: 1.0 GiB fine, 16 MiB coarse -- the walk reads it first and goes to the fine field only near a
+		// surface.  Automatic above 256 MiB of fine field; bm_scene_set_coarse_field / BM_COARSE_FIELD=0|1 force it.
+		view_.coarse_field = nullptr;
+		view_.cc_x = view_.cc_xy = 0;
+		view_.cc_plane = 0;
+		int mode = coarse_mode_;
+		if (const char* e = std::getenv("BM_COARSE_FIELD")) mode = std::atoi(e) != 0 ? 1 : 0;
+		if (mode > 0 || (mode < 0 && field.size() >= (256ull << 20))) {
+			std::vector<uint8_t> coarse;
+			world.build_coarse_field(field, coarse);
+			const int ccx = d.cells / 4 + 2;
+			BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_coarse_field_), coarse.size()));
+			BM_HIP(hipMemcpy(d_coarse_field_, coarse.data(), coarse.size(), hipMemcpyHostToDevice));
+			view_.cc_x = ccx;
+			view_.cc_xy = ccx * ccx;
+			view_.cc_plane = static_cast<uint32_t>(coarse.size() / 8);
+			view_.coarse_field = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(d_coarse_field_) - static_cast<uintptr_t>(3) * (1 + ccx + ccx * ccx));
+			cube_field_bytes_ += coarse.size();
+		}
 	}
 	view_.cells = d.cells;
 	view_.cells_height = d.cells_height;
@@ -596,8 +629,10 @@ int Scene::preload_all() {
 int Scene::frame_begin(hipStream_t stream) {
 	if (failed_) { set_error("a streaming batch failed on this scene: call bm_scene_reset_residency / bm_scene_preload_all"); return BM_ESTATE; }
 	FrameStream* fs = nullptr;
+	bool created = false;
 	for (FrameStream& f : frame_streams_) if (f.stream == stream) { fs = &f; break; }
 	if (!fs) {
+		created = true;
 		if (frame_streams_.size() >= kMaxFrameStreams) {
 			// retire the entry that has been idle longest (a caller that keeps creating streams): its last frame must have
 			// finished before the entry -- and with it the ordering of the load stream behind that frame -- can go
@@ -616,11 +651,18 @@ int Scene::frame_begin(hipStream_t stream) {
 	}
 	// (a stream handle can be recycled by the runtime after its owner destroyed it: an entry that claims to have seen the
 	// latest batch is only trusted once that batch has actually completed)
-	if (fs->upload_seen < upload_seq_ || (upload_seq_ > 0 && hipEventQuery(ev_upload_) == hipErrorNotReady)) {
+	// (the event is only queried for an entry that claims to be up to date and was not made by this call; a stream that has
+	// waited is not asked to wait again, and only the query's own "not ready" status is cleared -- never a sticky error of the
+	// caller's that happens to be pending on this thread)
+	bool must_wait = fs->upload_seen < upload_seq_;
+	if (!must_wait && upload_seq_ > 0 && !created) {
+		const hipError_t q = hipEventQuery(ev_upload_);
+		if (q == hipErrorNotReady) { (void)hipGetLastError(); must_wait = true; }
+	}
+	if (must_wait) {
 		BM_HIP(hipStreamWaitEvent(stream, ev_upload_, 0)); // ev_upload_ is re-recorded behind every batch: waiting for it covers all earlier ones
 		fs->upload_seen = upload_seq_;
 	}
-	(void)hipGetLastError(); // hipErrorNotReady is a status, not a failure
 	fs->last_use = ++frame_seq_;
 	return 0;
 }
@@ -662,13 +704,17 @@ int Scene::service_ring(int ring, uint32_t count) {
 	for (uint32_t i = 0; i < count; ++i) {
 		const int px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
 		if (px < 0 || py < 0 || pz < 0 || px >= d.cells || py >= d.cells || pz >= d.cells_height) {
+			// (the ring's counter is still set and the requested bits still stand: every later call would fail the same way while
+			// frames went on as if nothing had happened -- mark the scene failed, recovery is a residency reset)
 			set_error("brick request ring holds a position outside the world");
+			failed_ = true;
 			return BM_ESTATE;
 		}
 		const HostSupercell& c = world.supercells[d.supercell_id(px / kSupercell, py / kSupercell, pz / kSupercell)];
 		const uint32_t word = c.indices[static_cast<uint32_t>((px % kSupercell) + (py % kSupercell) * kSupercell + (pz % kSupercell) * kSupercell * kSupercell)];
 		if (!(word & BM_BRICK_LOADED_BIT) || (word & BM_BRICK_INDEX_BITS) >= c.bricks.size()) {
 			set_error("brick request ring names an empty brick");
+			failed_ = true;
 			return BM_ESTATE;
 		}
 	}
@@ -778,8 +824,16 @@ int Scene::process_load_queue(uint32_t* serviced) {
 	}
 	if (int e = order_load_stream_behind_frames()) return e; // the ring is complete once every frame that may append to it has ended
 	const int ring = ring_cur_;
-	BM_HIP(hipMemcpyAsync(h_count_[ring], d_load_count_[ring], sizeof(uint32_t), hipMemcpyDeviceToHost, load_stream_));
-	BM_HIP(hipMemcpyAsync(h_positions_[ring], d_load_queue_[ring], static_cast<size_t>(queue_cap_) * 3 * sizeof(int), hipMemcpyDeviceToHost, load_stream_));
+	// the count is not known on the host without waiting for the frame: a small kernel copies count + the entries that exist into
+	// the pinned (device-mapped) mirrors -- min(count, capacity) x 12 bytes over PCIe instead of the ring's whole capacity
+	{
+		int* dev_positions = nullptr;
+		uint32_t* dev_count = nullptr;
+		BM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_positions), h_positions_[ring], 0));
+		BM_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_count), h_count_[ring], 0));
+		launch_snapshot_ring(d_load_queue_[ring], d_load_count_[ring], dev_positions, dev_count, static_cast<uint32_t>(queue_cap_), load_stream_);
+		BM_HIP(hipGetLastError());
+	}
 	BM_HIP(hipEventRecord(ev_snapshot_, load_stream_));
 	snapshot_pending_ = true;
 	ring_snapshot_ = ring;

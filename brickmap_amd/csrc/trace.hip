@@ -85,7 +85,8 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #else
 #define BM_TIMED DBG
 #endif
-template <bool DBG>
+// COARSE: the walk reads the coarse level of the cube field first (scenes that have one: DeviceScene::coarse_field)
+template <bool DBG, bool COARSE = false>
 // (the instrumented variant carries hit records and counters: it gets the registers instead of the occupancy)
 __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, float4* __restrict__ accum,
 												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters,
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				if (need_setup) {
 					if (shadow) r.n = mk(0.f, 0.f, 0.f); // connect passes a zeroed normal (kernel.cu:338)
 					pstate = shadow ? P_SHD_DONE : P_EXT_DONE;
-					const int st = ray_setup<DBG>(sc, ro, rd, r, tally);
+					const int st = ray_setup<DBG, COARSE>(sc, ro, rd, r, tally);
 					state = (st == ST_NEED && shadow) ? ST_CONN : st;
 				}
 				BM_MARK(4, t_sub); // ray set-up
@@ -431,8 +432,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					if (BM_TIMED) { runsJ++; lanesJ += walkers; }
 					if (state == ST_JUMP || state == ST_OUTER) {
 						int st;
-						if (!(r.cube & kCubeNoJump)) st = field_jump<DBG>(sc, r, tally);
-						else st = field_step<DBG>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
+						if (!(r.cube & kCubeNoJump)) st = field_jump<DBG, true, COARSE>(sc, r, tally);
+						else st = field_step<DBG, COARSE>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
 						state = (st == ST_NEED && shadow) ? ST_CONN : st;
 					}
 					if (BM_JUMP_PASSES > 1) { // another pass right away while most of the walkers are still walking (saves a scheduler round)
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				for (int k = 0; k < BM_STEPS_PER_ROUND; ++k) {
 					if (BM_TIMED) { runsA++; lanesA += __popcll(__ballot(state == ST_OUTER)); }
 					if (state == ST_OUTER) {
-						const int st = field_step<DBG>(sc, r, tally);
+						const int st = field_step<DBG, COARSE>(sc, r, tally);
 						state = (st == ST_NEED && shadow) ? ST_CONN : st;
 					}
 				}
@@ -504,6 +505,18 @@ __global__ void move_pools(const PoolMove* __restrict__ moves, uint32_t* __restr
 	if (threadIdx.x == 0) pool_base[m.supercell] = m.dst;
 }
 
+// Overlapped request servicing: copy the ring's count and its first min(count, capacity) entries into the pinned host mirror,
+// straight from the device (the host buffer is mapped): what travels over PCIe is what was requested, not the ring's capacity
+// (the count is only known on the device at this point -- the host never waits for the frame; Scene.cpp:200-210 reads both
+// with blocking copies).  One small grid on the load stream, behind the frames that may still append to the ring.
+__global__ void snapshot_ring(const int* __restrict__ queue, const uint32_t* __restrict__ count, int* __restrict__ host_positions, uint32_t* __restrict__ host_count,
+							  uint32_t capacity) {
+	const uint32_t n = min(*count, capacity);
+	const uint32_t words = n * 3u;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < words; i += gridDim.x * blockDim.x) host_positions[i] = queue[i];
+	if (blockIdx.x == 0 && threadIdx.x == 0) *host_count = *count; // (the caller clamps it, like kernel.cu:409 / Scene.cpp:203)
+}
+
 // blit_onto_framebuffer (kernel.cu:348-364) into an offscreen float4 buffer
 __global__ void resolve_kernel(const float4* __restrict__ accum, float4* __restrict__ out, long long n) {
 	const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -536,8 +549,8 @@ __global__ void debug_sky_kernel(const FrameConstants fc, int n, const float* __
 // ---- host-callable launchers (kernels.h)
 int trace_blocks_per_cu(bool instrumented) {
 	int n = 0;
-	const hipError_t e = instrumented ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<true>, 256, 0)
-									  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<false>, 256, 0);
+	const hipError_t e = instrumented ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<true, false>, 256, 0)
+									  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<false, false>, 256, 0);
 	return e == hipSuccess && n > 0 ? n : 1;
 }
 
@@ -549,17 +562,18 @@ void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameCo
 	if (chunks <= 0) return;
 	long long blocks = (chunks + 15) / 16; // never more workgroups than 64-pixel groups
 	if (blocks > resident_blocks) blocks = resident_blocks;
-	if (instrumented)
-		hipLaunchKernelGGL(trace_paths<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc_dev, reinterpret_cast<float4*>(accum), dbg,
-						   counters, work_counter);
-	else
+	const bool coarse = sc.coarse_field != nullptr;
 #ifdef BM_PHASE_TIMING
-		hipLaunchKernelGGL(trace_paths<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc_dev, reinterpret_cast<float4*>(accum), nullptr,
-						   counters, work_counter);
+	DeviceCounters* const plain_counters = counters;
 #else
-		hipLaunchKernelGGL(trace_paths<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc_dev, reinterpret_cast<float4*>(accum), nullptr,
-						   nullptr, work_counter);
+	DeviceCounters* const plain_counters = nullptr;
 #endif
+	const dim3 grid(static_cast<unsigned>(blocks)), block(256);
+	float4* const acc4 = reinterpret_cast<float4*>(accum);
+	if (instrumented && coarse) hipLaunchKernelGGL((trace_paths<true, true>), grid, block, 0, stream, sc, fc_dev, acc4, dbg, counters, work_counter);
+	else if (instrumented) hipLaunchKernelGGL((trace_paths<true, false>), grid, block, 0, stream, sc, fc_dev, acc4, dbg, counters, work_counter);
+	else if (coarse) hipLaunchKernelGGL((trace_paths<false, true>), grid, block, 0, stream, sc, fc_dev, acc4, nullptr, plain_counters, work_counter);
+	else hipLaunchKernelGGL((trace_paths<false, false>), grid, block, 0, stream, sc, fc_dev, acc4, nullptr, plain_counters, work_counter);
 }
 
 void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const uint32_t* indices_queue, uint32_t* arena, uint32_t count,
@@ -572,6 +586,10 @@ void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const ui
 void launch_pool_moves(const PoolMove* moves, uint32_t count, uint32_t* arena, uint32_t* pool_base, hipStream_t stream) {
 	if (count == 0) return;
 	hipLaunchKernelGGL(move_pools, dim3(count), dim3(256), 0, stream, moves, arena, pool_base);
+}
+
+void launch_snapshot_ring(const int* queue, const uint32_t* count, int* host_positions, uint32_t* host_count, uint32_t capacity, hipStream_t stream) {
+	hipLaunchKernelGGL(snapshot_ring, dim3(32), dim3(256), 0, stream, queue, count, host_positions, host_count, capacity);
 }
 
 void launch_resolve(const float* accum, float* out, long long n, hipStream_t stream) {

@@ -90,7 +90,7 @@ __device__ __forceinline__ void unpack_walk(const DeviceScene& sc, const uint4& 
 	r.sx = __builtin_amdgcn_sbfe(static_cast<int>(meta), kMetaSxShift, 2);
 	r.stepy = __builtin_amdgcn_sbfe(static_cast<int>(meta), kMetaSyShift, 2) << 11;
 	r.stepz = __builtin_amdgcn_sbfe(static_cast<int>(meta), kMetaSzShift, 2) << 22;
-	r.field_off = __umul24((meta >> kMetaOctShift) & 7u, sc.cf_plane);
+	r.field_off = ((meta >> kMetaOctShift) & 7u) * sc.cf_plane; // (a plane of the widest world has more than 2^24 bytes: no 24-bit multiply here)
 	r.last_axis = static_cast<int>((meta >> kMetaAxisShift) & 3u) - 1;
 }
 __device__ __forceinline__ uint32_t meta_after_walk(uint32_t meta, const RayState& r) {

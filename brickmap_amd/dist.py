@@ -16,11 +16,98 @@ independent path and every rank holds a full scene replica, so the job can be cu
   from one N x spp render only in floating-point association (~1e-7 relative).
 
 No collective sits on the data path of the render itself.
+
+The exchange itself lives behind the C-ABI (include/brickmap.h "multi-GPU": bm_comm_create / bm_gather_frame / bm_reduce_frame,
+csrc/comm.hip -- grouped ncclSend / ncclRecv into one stacked buffer + one assembly kernel): `Comm` wraps it, and FrameGatherer /
+FrameReducer use it whenever the process group's backend is RCCL ("nccl") and the frames are device tensors.  torch.distributed
+then only carries the 128-byte communicator id from rank 0 to the others.  The torch.distributed.gather / reduce path remains for
+gloo (the CPU tests) and can be forced with BM_DIST_TORCH=1.
 """
+import ctypes as C
+import os
+
 import numpy as np
 
 DEFAULT_BAND_ROWS = 16  # one row of 16x16 tiles
 _cache = {}  # receive buffers / row indices, keyed by the gather's shape (per-frame gathers reuse them)
+
+
+class Comm:
+    """bm_comm (include/brickmap.h): an RCCL communicator of the C-ABI, one rank per GPU.  `unique_id` is the 128 bytes of
+    bm_comm_unique_id made by ONE rank and carried to the others by the caller."""
+
+    def __init__(self, device, rank, world, unique_id):
+        from . import _lib
+        self._L = _lib.load()
+        self._check = _lib.check
+        self.device, self.rank, self.world = int(device), int(rank), int(world)
+        assert len(unique_id) == 128
+        self._id = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        h = C.c_void_p()
+        self._check(self._L.bm_comm_create(self.device, self.rank, self.world, self._id, C.byref(h)))
+        self.handle = h
+
+    @staticmethod
+    def unique_id():
+        from . import _lib
+        buf = (C.c_ubyte * 128)()
+        _lib.check(_lib.load().bm_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_process_group(cls, device, group=None):
+        """One communicator over the ranks of a torch.distributed group: rank 0 makes the id, a broadcast carries it."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        on_device = dist.get_backend(group) == "nccl"
+        t = torch.zeros(128, dtype=torch.uint8, device=torch.device("cuda", device) if on_device else torch.device("cpu"))
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(cls.unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(device, rank, world, bytes(t.cpu().numpy().tobytes()))
+
+    def gather_frame(self, packed, frame, height, width, band_rows, root=0, stream=None):
+        """bm_gather_frame: `packed` = this rank's [local_rows, width, 4] float32 device tensor, `frame` = [height, width, 4] on the root."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(packed.device).cuda_stream
+        self._check(self._L.bm_gather_frame(self.handle, C.c_void_p(packed.data_ptr()), C.c_void_p(frame.data_ptr()) if frame is not None else None,
+                                            int(height), int(width), int(band_rows), int(root), C.c_void_p(stream)))
+
+    def reduce_frame(self, src, dst, root=0, stream=None):
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(src.device).cuda_stream
+        self._check(self._L.bm_reduce_frame(self.handle, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()) if dst is not None else None,
+                                            int(src.numel()), int(root), C.c_void_p(stream)))
+
+    def barrier(self, stream=None):
+        import torch
+        self._check(self._L.bm_comm_barrier(self.handle, C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)))
+
+    def selftest(self, stream=None):
+        import torch
+        self._check(self._L.bm_comm_selftest(self.handle, C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._L.bm_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _use_capi(collective, group, device):
+    """The C-ABI exchange serves RCCL groups with device frames; gloo (CPU tests) and BM_DIST_TORCH=1 keep torch.distributed's."""
+    import torch
+    import torch.distributed as dist
+    return (collective and dist.is_initialized() and dist.get_backend(group) == "nccl" and torch.device(device).type == "cuda"
+            and os.environ.get("BM_DIST_TORCH", "0") != "1")
 
 
 def shard_rows(height, band_rows, rank, world):
@@ -112,8 +199,18 @@ class FrameGatherer:
         self.out = torch.empty((height, width, channels), dtype=dtype, device=buf_device) if root else None
         self.work = None
         self.local = None
+        self.width = width
+        # the exchange behind the C-ABI (bm_gather_frame) on a side stream: it runs behind the snapshot and beside the next frame
+        self.comm = None
+        if _use_capi(self.collective, group, self.out_device) and channels == 4 and dtype == torch.float32:
+            self.comm = Comm.from_process_group(self.out_device.index if self.out_device.index is not None else torch.cuda.current_device(), group)
+            self.side = torch.cuda.Stream(device=self.out_device)
+            self.snap = torch.cuda.Event()
+            self.recv_all = self.recv = self.index = None  # (the root's receive buffer belongs to the communicator)
+            self.pending = False
 
     def start(self, local):
+        import torch
         import torch.distributed as dist
         assert self.work is None and self.local is None, "finish() the previous gather first"
         assert local.shape[0] == self.counts[self.rank]
@@ -121,6 +218,13 @@ class FrameGatherer:
             self.local = local
             return
         self.send[: local.shape[0]].copy_(local)  # snapshot: the caller may keep accumulating into `local`
+        if self.comm is not None:
+            assert not self.pending, "finish() the previous gather first"
+            self.snap.record(torch.cuda.current_stream(self.out_device))
+            self.side.wait_event(self.snap)
+            self.comm.gather_frame(self.send, self.out, self.height, self.width, self.band_rows, root=self.dst, stream=self.side.cuda_stream)
+            self.pending = True
+            return
         self.work = dist.gather(self.send, gather_list=self.recv, dst=self.dst, group=self.group, async_op=True)
 
     def finish(self):
@@ -128,6 +232,12 @@ class FrameGatherer:
         if not self.collective:
             out, self.local = self.local, None
             return out
+        if self.comm is not None:
+            if not self.pending:
+                return None
+            torch.cuda.current_stream(self.out_device).wait_stream(self.side)  # like Work.wait(): the current stream, not the host
+            self.pending = False
+            return self.out if self.rank == self.dst else None
         if self.work is None:
             return None
         self.work.wait()
@@ -158,8 +268,15 @@ class FrameReducer:
         self.buf = torch.zeros((height, width, channels), dtype=dtype or torch.float32, device=buf_device)
         self.work = None
         self.local = None
+        self.comm = None
+        if _use_capi(self.collective, group, self.out_device) and (dtype or torch.float32) == torch.float32:
+            self.comm = Comm.from_process_group(self.out_device.index if self.out_device.index is not None else torch.cuda.current_device(), group)
+            self.side = torch.cuda.Stream(device=self.out_device)
+            self.snap = torch.cuda.Event()
+            self.pending = False
 
     def start(self, local):
+        import torch
         import torch.distributed as dist
         assert self.work is None and self.local is None, "finish() the previous reduction first"
         assert tuple(local.shape) == tuple(self.buf.shape)
@@ -167,12 +284,26 @@ class FrameReducer:
             self.local = local
             return
         self.buf.copy_(local)  # snapshot: the caller may keep accumulating into `local`
+        if self.comm is not None:
+            assert not self.pending, "finish() the previous reduction first"
+            self.snap.record(torch.cuda.current_stream(self.out_device))
+            self.side.wait_event(self.snap)
+            self.comm.reduce_frame(self.buf, self.buf, root=self.dst, stream=self.side.cuda_stream)  # in place, like dist.reduce
+            self.pending = True
+            return
         self.work = dist.reduce(self.buf, dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         if not self.collective:
             out, self.local = self.local, None
             return out
+        if self.comm is not None:
+            import torch
+            if not self.pending:
+                return None
+            torch.cuda.current_stream(self.out_device).wait_stream(self.side)
+            self.pending = False
+            return self.buf if self.rank == self.dst else None
         if self.work is None:
             return None
         self.work.wait()

@@ -221,6 +221,37 @@ BM_API int bm_sched_stats_read(bm_scene* scene, bm_sched_stats* out);
  * walked an 8^3 brick, the sum of their loop lengths (longest walk among the lanes of the pass) and the sum of all lanes' walk lengths */
 BM_API int bm_sched_detail_read(bm_scene* scene, uint64_t* out8);
 
+/* ---- multi-GPU: the frame's interleaved row bands, one rank per GPU, gathered to the root over RCCL / xGMI.
+ * No counterpart in the reference (single GPU: src/main.cpp:89 computes `multi_gpu` and never uses it).  Every rank holds a full
+ * scene replica and renders its shard (band_rows / shard_rank / shard_count of bm_frame_params) into a packed local buffer;
+ * bm_gather_frame is the one exchange per frame: ncclGroupStart / the root's ncclRecv from every peer into one stacked buffer /
+ * the peers' ncclSend / ncclGroupEnd, then one kernel on the root that puts row y where it belongs.  RCCL is bound at run time
+ * (dlopen of librccl.so.1 on the first call): a process that already holds an RCCL (torch.distributed, a host linked against
+ * /opt/rocm/lib/librccl.so) shares it.  Error codes: 20000 + ncclResult_t. */
+typedef struct bm_comm bm_comm;
+#define BM_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+/* ncclGetUniqueId: called by ONE rank; the 128 bytes reach the others by the host's own means (MPI_Bcast, a file, a socket) */
+BM_API int bm_comm_unique_id(void* id128);
+/* ncclCommInitRank on `device`: collective over all `world` ranks (one process or thread per GPU) */
+BM_API int bm_comm_create(int device, int rank, int world, const void* id128, bm_comm** out);
+BM_API void bm_comm_destroy(bm_comm* comm);
+BM_API int bm_comm_info(bm_comm* comm, int* rank, int* world);
+/* packed_dev: this rank's bm_local_rows x width float4 (what bm_render_frame accumulated for its shard); frame_dev: height x width
+ * float4 on the root (ignored elsewhere).  Enqueued on hip_stream: ordered behind the frame that produced packed_dev; the host
+ * does not wait.  The row-to-rank map is that of bm_frame_params: row y belongs to rank (y / band_rows) % world. */
+BM_API int bm_gather_frame(bm_comm* comm, const float* packed_dev, float* frame_dev, int height, int width, int band_rows, int root,
+                           void* hip_stream);
+/* sample-sharded frames (every rank renders the whole frame with its own sample_base slice): ncclReduce(sum) to the root */
+BM_API int bm_reduce_frame(bm_comm* comm, const float* in_dev, float* out_dev, int64_t n_floats, int root, void* hip_stream);
+/* all ranks have reached this point (an all-reduce of one word, then the host waits for the stream) */
+BM_API int bm_comm_barrier(bm_comm* comm, void* hip_stream);
+/* start-up check of the transport: a grouped send / receive round the ring of ranks and an all-reduce, data verified */
+BM_API int bm_comm_selftest(bm_comm* comm, void* hip_stream);
+/* test door: the root's assembly kernel alone, on one GPU -- frame row y <- packed row of rank (y / band_rows) % world, taken from
+ * own_packed_dev for rank `me` and from stacked_dev (world x max_rows x width float4, rank-major) for everybody else */
+BM_API int bm_debug_assemble_frame(int device, const float* own_packed_dev, const float* stacked_dev, float* frame_dev, int height, int width,
+                                   int band_rows, int world, int me, int max_rows, void* hip_stream);
+
 /* ---- wavefront mode: launch_kernels exactly as the reference schedules it (kernel.cu:366-439) --
  * one call traces ONE segment of every path in flight: primary_rays tops the work queue up to `queue_size`
  * (ray_queue_buffer_size, variables.h:61), extend, shade (survivors -> next queue, shadow rays -> shadow queue),

@@ -75,12 +75,22 @@ public:
 	void preload_all() { BM_CHECKED(bm_scene_preload_all(gpuScene.handle)); }
 };
 
+// Which part of the frame this process renders (no counterpart in the reference, which is single-GPU: main.cpp:89 computes
+// `multi_gpu` and never uses it): the frame's rows are dealt out in bands of `band_rows` rows, band b to rank b % count, and
+// a rank's rows are packed in increasing y into its State's blit_buffer.  {0, 1} = the whole frame.
+struct Shard {
+	int rank = 0, count = 1;
+	int band_rows = 16; // one row of 16x16-pixel tiles
+};
+
 struct State { // state.h:5-34 without the wavefront queues and the GL interop
 	vec4* blit_buffer = nullptr; // device memory, float4 per pixel: rgb = radiance sum, a = terminated paths
 	size_t screen_width, screen_height;
 	int device;
+	Shard shard;           // the rows blit_buffer holds (default: all of them)
+	size_t local_rows = 0; // = screen_height for the whole frame
 
-	State(size_t width, size_t height, int device_ = 0) : screen_width(width), screen_height(height), device(device_) { alloc(); }
+	State(size_t width, size_t height, int device_ = 0, Shard shard_ = {}) : screen_width(width), screen_height(height), device(device_), shard(shard_) { alloc(); }
 	~State() { bm_buffer_free(device, blit_buffer); }
 	void screen_resize(size_t width, size_t height) {
 		screen_width = width;
@@ -91,9 +101,13 @@ struct State { // state.h:5-34 without the wavefront queues and the GL interop
 
 private:
 	void alloc() {
+		bm_frame_params fp{};
+		fp.width = static_cast<int32_t>(screen_width); fp.height = static_cast<int32_t>(screen_height);
+		fp.band_rows = shard.count > 1 ? shard.band_rows : fp.height; fp.shard_rank = shard.rank; fp.shard_count = shard.count;
+		local_rows = static_cast<size_t>(bm_local_rows(&fp));
 		void* p = nullptr;
-		BM_CHECKED(bm_buffer_alloc(device, screen_width * screen_height * sizeof(vec4), &p));
-		BM_CHECKED(bm_buffer_zero(device, p, screen_width * screen_height * sizeof(vec4), nullptr));
+		BM_CHECKED(bm_buffer_alloc(device, screen_width * (local_rows ? local_rows : 1) * sizeof(vec4), &p));
+		BM_CHECKED(bm_buffer_zero(device, p, screen_width * (local_rows ? local_rows : 1) * sizeof(vec4), nullptr));
 		blit_buffer = static_cast<vec4*>(p);
 	}
 };
@@ -115,9 +129,9 @@ inline bm_frame_params frame_params(const State& state, int max_bounces) {
 	fp.spp = 1;
 	fp.max_bounces = max_bounces;
 	fp.base_frame = 1;
-	fp.band_rows = fp.height;
-	fp.shard_rank = 0;
-	fp.shard_count = 1;
+	fp.band_rows = state.shard.count > 1 ? state.shard.band_rows : fp.height;
+	fp.shard_rank = state.shard.rank;
+	fp.shard_count = state.shard.count;
 	fp.sun_position[0] = sun_position.x;
 	fp.sun_position[1] = sun_position.y;
 	return fp;
@@ -144,18 +158,48 @@ inline int launch_kernels(State& state, vec4* blit_buffer, Scene::GPUScene gpuSc
 		reset_buffer = true;
 	}
 	if (reset_buffer) {
-		BM_CHECKED(bm_buffer_zero(state.device, blit_buffer, state.screen_width * state.screen_height * sizeof(vec4), nullptr));
+		BM_CHECKED(bm_buffer_zero(state.device, blit_buffer, state.screen_width * state.local_rows * sizeof(vec4), nullptr));
 		sample_base = 0;
 	}
 	const bm_camera cam = detail::camera_to_c();
 	bm_frame_params fp = detail::frame_params(state, max_bounces);
 	fp.spp = spp;
 	fp.sample_base = sample_base;
+	// a shard has few pixels and (usually) many samples: (4x4 chunk, sample) work items keep the persistent waves fed
+	if (state.shard.count > 1) fp.flags |= BM_FLAG_SAMPLE_ITEMS;
 	BM_CHECKED(bm_render_frame(gpuScene.handle, &cam, &fp, reinterpret_cast<float*>(blit_buffer), nullptr, nullptr));
 	BM_CHECKED(bm_synchronize(gpuScene.handle));
 	sample_base += spp;
 	last = camera;
 	return 0; // the reference always returns cudaSuccess (kernel.cu:438)
+}
+
+// ---- multi-GPU: one process (or thread) per GPU, every one with its own Scene replica, State shard and Comm.
+// The per-frame loop of main.cpp:142-147 becomes, on every rank:
+//     launch_kernels(state, state.blit_buffer, scene.gpuScene, spp);      // this rank's bands (state.shard)
+//     scene.process_load_queue();
+//     gather_frame(comm, state, frame_on_root);                           // ncclSend / ncclRecv + assembly, RCCL over xGMI
+// INTEGRATION.md has the whole program.
+struct Comm {
+	bm_comm* handle = nullptr;
+	int rank = 0, world = 1;
+	// ncclGetUniqueId: called on ONE rank; hand the 128 bytes to the others (MPI_Bcast, a file, a socket)
+	static void unique_id(unsigned char id[BM_COMM_ID_BYTES]) { BM_CHECKED(bm_comm_unique_id(id)); }
+	Comm(int device, int rank_, int world_, const unsigned char id[BM_COMM_ID_BYTES]) : rank(rank_), world(world_) {
+		BM_CHECKED(bm_comm_create(device, rank, world, id, &handle));
+	}
+	~Comm() { bm_comm_destroy(handle); }
+	Comm(const Comm&) = delete;
+	Comm& operator=(const Comm&) = delete;
+	void barrier() { BM_CHECKED(bm_comm_barrier(handle, nullptr)); }
+};
+
+// The exchange of one frame: every rank's packed bands to `root`, assembled there into frame_on_root (height x width float4,
+// device memory of the root; ignored on the other ranks).  Enqueued on the default stream behind the frame; returns at once.
+inline void gather_frame(Comm& comm, const State& state, vec4* frame_on_root, int root = 0) {
+	BM_CHECKED(bm_gather_frame(comm.handle, reinterpret_cast<const float*>(state.blit_buffer), reinterpret_cast<float*>(frame_on_root),
+							   static_cast<int>(state.screen_height), static_cast<int>(state.screen_width), state.shard.count > 1 ? state.shard.band_rows : static_cast<int>(state.screen_height),
+							   root, nullptr));
 }
 
 // The reference's own schedule.  RayQueue* queue / queue2 and ShadowQueue* shadowQueue of the reference signature

@@ -28,7 +28,11 @@ def main():
     state = bm.State(W, H, device=0, band_rows=band, shard_rank=0, shard_count=1)
     p = bm.FrameParams(W, H, spp=2, max_bounces=3, flags=bm.BM_FLAG_SAMPLE_ITEMS, band_rows=band, shard_rank=0, shard_count=1)
     gatherer = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev, force_collective=True)
-    assert gatherer.collective and not gatherer.stage_on_cpu and gatherer.send.is_cuda and gatherer.recv_all.is_cuda
+    # RCCL group + device frames: the exchange is the C-ABI's (bm_comm_create / bm_gather_frame, csrc/comm.hip)
+    assert gatherer.collective and not gatherer.stage_on_cpu and gatherer.send.is_cuda and gatherer.comm is not None
+    assert (gatherer.comm.rank, gatherer.comm.world) == (0, 1)
+    gatherer.comm.selftest()  # grouped ncclSend / ncclRecv (to itself) + all-reduce through the communicator, data verified
+    gatherer.comm.barrier()
     frames = []
     for step in range(3):  # the pipelined loop of bench.py: finish the previous gather, start the next one behind the frame
         scene.render(cam, p, state.blit_buffer)
@@ -42,7 +46,7 @@ def main():
     assert torch.equal(frames[-1], state.blit_buffer)  # world 1: the gathered frame is the local one, bit for bit
     assert float(frames[0][..., 3].min()) == 2.0 and float(frames[2][..., 3].min()) == 6.0
     reducer = bm.dist.FrameReducer(H, W, device=dev, force_collective=True)
-    assert reducer.collective and reducer.buf.is_cuda
+    assert reducer.collective and reducer.buf.is_cuda and reducer.comm is not None
     reducer.start(state.blit_buffer)
     red = reducer.finish()
     torch.cuda.synchronize()
@@ -51,6 +55,20 @@ def main():
     t = torch.tensor([1.25], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert float(t.item()) == 1.25
+    # the torch.distributed exchange stays available (gloo tests, BM_DIST_TORCH=1): same frames
+    os.environ["BM_DIST_TORCH"] = "1"
+    g2 = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev, force_collective=True)
+    assert g2.comm is None and g2.recv_all.is_cuda
+    g2.start(state.blit_buffer)
+    assert torch.equal(g2.finish(), state.blit_buffer)
+    del os.environ["BM_DIST_TORCH"]
+    # a second communicator from raw C-ABI calls, as a C++ host would make it (no torch.distributed involved)
+    c2 = bm.dist.Comm(0, 0, 1, bm.dist.Comm.unique_id())
+    out = torch.empty_like(state.blit_buffer)
+    c2.gather_frame(state.blit_buffer, out, H, W, band)
+    torch.cuda.synchronize()
+    assert torch.equal(out, state.blit_buffer)
+    c2.close()
     one = bm.dist.gather_frame(state.blit_buffer, H, band)  # world 1 short-cut returns the local frame
     assert one is state.blit_buffer
     scene.close()

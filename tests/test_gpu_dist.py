@@ -30,6 +30,41 @@ def test_nccl_process_group_with_one_rank_moves_frames():
     assert r.returncode == 0 and "NCCL_DRY_RUN_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
+def test_root_assembly_kernel_with_three_ranks_on_one_gpu():
+    """The kernel behind bm_gather_frame that puts every rank's packed rows where they belong, with world = 3 (ragged last band,
+    unequal shards): three shards rendered on this GPU, stacked as the root's receive buffer would hold them, assembled by
+    bm_debug_assemble_frame for every choice of root -- the frame is the unsharded render bit for bit."""
+    import ctypes as C
+    import torch
+    import brickmap_amd as bm
+    from brickmap_amd import _lib
+    L = _lib.load()
+    G, W, H, band, world = 256, 200, 120, 16, 3
+    scene = bm.Scene(G, G, device=0).generate().preload_all()
+    cam = bm.Camera(position=(G / 2, G / 8, 0.8 * G), horizontal_angle=0.8, vertical_angle=-0.5).update()
+    full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    scene.render(cam, bm.FrameParams(W, H, spp=2, max_bounces=3), full)
+    shards = []
+    for r in range(world):
+        p = bm.FrameParams(W, H, spp=2, max_bounces=3, band_rows=band, shard_rank=r, shard_count=world)
+        a = torch.zeros((bm.local_rows(p), W, 4), dtype=torch.float32, device="cuda:0")
+        scene.render(cam, p, a)
+        shards.append(a)
+    max_rows = max(a.shape[0] for a in shards)
+    assert sorted(a.shape[0] for a in shards) != [max_rows] * world  # unequal shards: 48 / 40 / 32 rows
+    for me in range(world):
+        stacked = torch.full((world, max_rows, W, 4), float("nan"), dtype=torch.float32, device="cuda:0")
+        for r in range(world):
+            if r != me:
+                stacked[r, : shards[r].shape[0]] = shards[r]
+        out = torch.empty_like(full)
+        _lib.check(L.bm_debug_assemble_frame(0, C.c_void_p(shards[me].data_ptr()), C.c_void_p(stacked.data_ptr()), C.c_void_p(out.data_ptr()), H, W, band, world, me,
+                                             max_rows, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int32), full.view(torch.int32)), f"root {me}"
+    scene.close()
+
+
 @pytest.mark.parametrize("extra", [[], ["--pipeline", "2"], ["--decomposition", "samples"]])
 def test_bench_multi_gpu_code_path_on_nccl_with_one_rank(extra):
     """bench.py's N > 1 path (RCCL process group, row-band shard with (chunk, sample) items, pipelined device gather,
@@ -65,6 +100,11 @@ def test_default_bench_line_schema():
     assert "1920x1080" in out["config"]["workload"] and out["config"]["spp_per_step"] == 1
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
-    assert "reference-equivalent" in rf["achieved_is"] and "VALU" in rf["limiter"] and rf["kernel_ms_avg"] <= out["ms_per_step"] * 1.05
+    assert "reference-equivalent" in rf["achieved_is"] and "VALU" in rf["limiter"] and "pmc_summary_config2" in rf["limiter_source"]
+    assert rf["kernel_ms_avg"] <= out["ms_per_step"] * 1.05
     assert rf["traffic"] and "r03_pmc_summary_config2.json" in rf["traffic_source"]
     assert out["multi_gpu_job_on_one_gpu"]["ms_per_step"] > 0 and out["north_star_4spp"]["roofline_frac"] > 0 and out["pipelined"]["ms_per_step"] > 0
+    # the scaling prediction the first real multi-GPU run is checked against: rank 0's shard of the 8-spp job at N = 2 / 4 / 8
+    pred = out["multi_gpu_prediction"]
+    assert set(pred["shard_kernel_ms"]) == {"2", "4", "8"} and all(v > 0 for v in pred["shard_kernel_ms"].values())
+    assert 1.0 < pred["predicted_speedup"]["2"] < pred["predicted_speedup"]["4"] < pred["predicted_speedup"]["8"] <= 8.5

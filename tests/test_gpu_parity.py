@@ -476,6 +476,23 @@ def test_cpp_headless_example_streams_and_renders(bm, torch_cuda, tmp_path):
     assert px.max() > 0 and len(np.unique(px)) > 16  # an actual image, not a constant
 
 
+def test_cpp_multi_gpu_example_with_one_rank(bm, torch_cuda, tmp_path):
+    """The C++ multi-GPU loop of INTEGRATION.md (Shard + Comm + gather_frame of include/brickmap.hpp, RCCL behind the C-ABI)
+    with one rank: communicator from a file-carried id, sharded State, bm_gather_frame every frame, barrier, resolve."""
+    import subprocess
+    from conftest import ROOT
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "examples")])
+    out = tmp_path / "mg.ppm"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([os.path.join(ROOT, "examples", "multi_gpu_main"), "0", "1", str(tmp_path / "id"), "256", "256", "160", "96", "12", "2", str(out)],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "1 ranks, 12 frames of 2 spp" in r.stdout
+    data = out.read_bytes()
+    px = np.frombuffer(data[len(b"P6\n160 96\n255\n"):], np.uint8)
+    assert len(px) == 160 * 96 * 3 and px.max() > 0 and len(np.unique(px)) > 16
+
+
 def test_scheduler_statistics(bm, orc, torch_cuda, scene256):
     cam, _ = cameras(bm, orc, 256)
     scene256.counters_reset()

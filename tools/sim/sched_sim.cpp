@@ -103,9 +103,19 @@ struct World {
 	}
 };
 static World g_w;
+static std::vector<uint8_t> g_coarse; // per octant and 4x4x4 block of (bordered coordinate + 15) >> 2: min of the fine bytes
+static int g_cb = 0; static size_t g_cplane = 0;
+static uint64_t g_lookups = 0, g_coarse_hits[4] = {0, 0, 0, 0}; // lookups answered by the coarse level for thresholds 2, 4, 8, 16
 
 static int lookup(Slot& s, const Params& P) {
 	const int v = g_w.F(s.oct, s.px, s.py, s.pz);
+	if (!g_coarse.empty() && v != 255) {
+		const int bx = (s.px + 16) >> 2, by = (s.py + 16) >> 2, bz = (s.pz + 16) >> 2;
+		const int c = g_coarse[s.oct * g_cplane + (size_t(bz - 3) * g_cb + (by - 3)) * g_cb + (bx - 3)];
+		g_lookups++;
+		const int th[4] = {2, 4, 8, 16};
+		for (int k = 0; k < 4; ++k) g_coarse_hits[k] += c >= th[k];
+	}
 	const bool possible = bm::jump_possible(s.tx, s.ty, s.tz);
 	s.cube = (uint32_t)v; s.nojump = !possible;
 	int st = (v >= P.jump_min && possible) ? S_JUMP : S_OUTER;
@@ -414,6 +424,16 @@ int main(int argc, char** argv) {
 	g_w.w.build_cube_field(g_w.field, 8);
 	g_w.cells = g_w.w.dims.cells; g_w.cells_h = g_w.w.dims.cells_height; g_w.cfx = g_w.cells + 2; g_w.plane = g_w.field.size() / 8; g_w.gs = float(G); g_w.gh = float(G);
 
+	if (getenv("BM_SIM_COARSE")) {
+		g_cb = g_w.cells / 4 + 2; const int cbz = g_w.cells_h / 4 + 2;
+		g_cplane = size_t(g_cb) * g_cb * cbz;
+		g_coarse.assign(g_cplane * 8, 255);
+		for (int o = 0; o < 8; ++o)
+			for (int z = -1; z <= g_w.cells_h; ++z) for (int y = -1; y <= g_w.cells; ++y) for (int x = -1; x <= g_w.cells; ++x) {
+				uint8_t& c = g_coarse[o * g_cplane + (size_t(((z + 16) >> 2) - 3) * g_cb + (((y + 16) >> 2) - 3)) * g_cb + (((x + 16) >> 2) - 3)];
+				c = std::min<uint8_t>(c, (uint8_t)g_w.F(o, x, y, z));
+			}
+	}
 	auto run = [&](const Params& P) {
 		Sim sim; sim.P = P; sim.P.nwaves = P.W * (1024 / (P.tiles > 1 ? P.tiles : 1)); sim.W_img = W; sim.H_img = H; sim.tiles_x = (W + 15) / 16; sim.tiles_y = (H + 15) / 16;
 		sim.total_chunks = uint32_t(sim.tiles_x) * sim.tiles_y * 16u;
@@ -473,6 +493,8 @@ int main(int argc, char** argv) {
 		}
 		printf("   brick loop %.1f cells;  sched+refill %.1fM instr;  total %.3fG wave instr, lanes/instr %.1f\n", S.brick_loop / std::max(1.0, S.brick_passes), S.instr[4] * scale / 1e6, total_instr * scale / 1e9,
 			   lane_instr / (total_instr - S.instr[4]));
+		if (g_lookups) printf("   coarse level (min over 4x4x4 blocks): of %.1fM field lookups, block-min >= 2 / 4 / 8 / 16: %.1f %% / %.1f %% / %.1f %% / %.1f %%\n", g_lookups / 1e6,
+							  100.0 * g_coarse_hits[0] / g_lookups, 100.0 * g_coarse_hits[1] / g_lookups, 100.0 * g_coarse_hits[2] / g_lookups, 100.0 * g_coarse_hits[3] / g_lookups);
 		printf("   frame %.3f ms (slowest SIMD at 2.4 GHz), SIMD issue busy %.1f %%, drain %.1f %% of wave lifetime\n", t_last / 2.4e6, 100.0 * busy / (t_last * nsimd), 100.0 * drain_sum / life_sum);
 		fflush(stdout);
 	};
