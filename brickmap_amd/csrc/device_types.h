@@ -30,14 +30,6 @@ struct DeviceScene {
 	const uint8_t* cube_field;
 	int cf_x, cf_xy;    // row / slice pitch in cells
 	uint32_t cf_plane;  // bytes per plane
-	// Coarse level of the cube field, or null (worlds whose fine field does not fit the caches): one byte per
-	// 4x4x4 block of cells and octant = the smallest fine byte of the block (255: border block).  A walk that finds >= kCoarseMin
-	// there uses it as its cube and never touches the fine field; the field only ever UNDER-reports free space, so the cells a
-	// ray visits -- and every hit -- are unchanged.  Indexed with the packed cell's fields >> 2; points 3 * (1 + cc_x + cc_xy)
-	// bytes BEFORE plane 0.
-	const uint8_t* coarse_field;
-	int cc_x, cc_xy;
-	uint32_t cc_plane;
 	int* load_queue;             // 3 ints per entry
 	uint32_t* load_queue_count;
 	uint32_t queue_cap;

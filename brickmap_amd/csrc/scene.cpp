@@ -279,8 +279,6 @@ void Scene::free_device() {
 	arena_close();
 	if (d_cube_field_) hipFree(d_cube_field_);
 	d_cube_field_ = nullptr;
-	if (d_coarse_field_) hipFree(d_coarse_field_);
-	d_coarse_field_ = nullptr;
 	d_index_grid_ = d_arena_ = d_pool_base_ = nullptr;
 	arena_capacity_ = arena_top_ = pool_bricks_ = 0;
 	on_device_ = false;
@@ -488,26 +486,6 @@ int Scene::allocate_device() {
 		view_.cf_plane = static_cast<uint32_t>(field.size() / 8);
 		view_.cube_field = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(d_cube_field_) - static_cast<uintptr_t>(15) * (1 + cfx + cfx * cfx));
 		cube_field_bytes_ = field.size();
-		// Coarse level (one byte per 4x4x4 cells and octant, 1/64 of the fine field): for worlds whose fine field cannot stay in
-		// the caches -- config 5: 1.0 GiB fine, 16 MiB coarse -- the walk reads it first and goes to the fine field only near a
-		// surface.  Automatic above 256 MiB of fine field; bm_scene_set_coarse_field / BM_COARSE_FIELD=0|1 force it.
-		view_.coarse_field = nullptr;
-		view_.cc_x = view_.cc_xy = 0;
-		view_.cc_plane = 0;
-		int mode = coarse_mode_;
-		if (const char* e = std::getenv("BM_COARSE_FIELD")) mode = std::atoi(e) != 0 ? 1 : 0;
-		if (mode > 0 || (mode < 0 && field.size() >= (256ull << 20))) {
-			std::vector<uint8_t> coarse;
-			world.build_coarse_field(field, coarse);
-			const int ccx = d.cells / 4 + 2;
-			BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_coarse_field_), coarse.size()));
-			BM_HIP(hipMemcpy(d_coarse_field_, coarse.data(), coarse.size(), hipMemcpyHostToDevice));
-			view_.cc_x = ccx;
-			view_.cc_xy = ccx * ccx;
-			view_.cc_plane = static_cast<uint32_t>(coarse.size() / 8);
-			view_.coarse_field = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(d_coarse_field_) - static_cast<uintptr_t>(3) * (1 + ccx + ccx * ccx));
-			cube_field_bytes_ += coarse.size();
-		}
 	}
 	view_.cells = d.cells;
 	view_.cells_height = d.cells_height;

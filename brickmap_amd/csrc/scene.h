@@ -31,7 +31,6 @@ public:
 
 	int init(int grid_size, int grid_height); // Scene::Scene: streams + pinned staging
 	int set_lod(int lod8, int lod2);
-	int set_coarse_field(int mode);
 	int set_queue_capacity(int cap);
 	int set_streaming_mode(int overlapped);
 	int generate(int threads);                // Scene::generate
@@ -107,8 +106,6 @@ private:
 	uint32_t* d_pool_base_ = nullptr;
 	uint32_t* d_arena_ = nullptr;
 	uint8_t* d_cube_field_ = nullptr;
-	uint8_t* d_coarse_field_ = nullptr; // coarse level of the cube field (big worlds only)
-	int coarse_mode_ = -1;              // -1: automatic (fine field >= 256 MiB), 0: never, 1: always
 	uint64_t cube_field_bytes_ = 0;
 	// two request rings: the blocking (reference-order) mode only uses ring 0; the overlapped mode alternates them so
 	// that a frame can raise requests while the previous frame's ring is being copied out and serviced

@@ -85,8 +85,7 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #else
 #define BM_TIMED DBG
 #endif
-// COARSE: the walk reads the coarse level of the cube field first (scenes that have one: DeviceScene::coarse_field)
-template <bool DBG, bool COARSE = false>
+template <bool DBG>
 // (the instrumented variant carries hit records and counters: it gets the registers instead of the occupancy)
 __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, float4* __restrict__ accum,
 												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters,
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				if (need_setup) {
 					if (shadow) r.n = mk(0.f, 0.f, 0.f); // connect passes a zeroed normal (kernel.cu:338)
 					pstate = shadow ? P_SHD_DONE : P_EXT_DONE;
-					const int st = ray_setup<DBG, COARSE>(sc, ro, rd, r, tally);
+					const int st = ray_setup<DBG>(sc, ro, rd, r, tally);
 					state = (st == ST_NEED && shadow) ? ST_CONN : st;
 				}
 				BM_MARK(4, t_sub); // ray set-up
@@ -432,8 +431,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					if (BM_TIMED) { runsJ++; lanesJ += walkers; }
 					if (state == ST_JUMP || state == ST_OUTER) {
 						int st;
-						if (!(r.cube & kCubeNoJump)) st = field_jump<DBG, true, COARSE>(sc, r, tally);
-						else st = field_step<DBG, COARSE>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
+						if (!(r.cube & kCubeNoJump)) st = field_jump<DBG>(sc, r, tally);
+						else st = field_step<DBG>(sc, r, tally); // tmax outside the range jump.h handles (first move of a ray that starts on a cell face)
 						state = (st == ST_NEED && shadow) ? ST_CONN : st;
 					}
 					if (BM_JUMP_PASSES > 1) { // another pass right away while most of the walkers are still walking (saves a scheduler round)
@@ -447,7 +446,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				for (int k = 0; k < BM_STEPS_PER_ROUND; ++k) {
 					if (BM_TIMED) { runsA++; lanesA += __popcll(__ballot(state == ST_OUTER)); }
 					if (state == ST_OUTER) {
-						const int st = field_step<DBG, COARSE>(sc, r, tally);
+						const int st = field_step<DBG>(sc, r, tally);
 						state = (st == ST_NEED && shadow) ? ST_CONN : st;
 					}
 				}
@@ -549,8 +548,8 @@ __global__ void debug_sky_kernel(const FrameConstants fc, int n, const float* __
 // ---- host-callable launchers (kernels.h)
 int trace_blocks_per_cu(bool instrumented) {
 	int n = 0;
-	const hipError_t e = instrumented ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<true, false>, 256, 0)
-									  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<false, false>, 256, 0);
+	const hipError_t e = instrumented ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<true>, 256, 0)
+									  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<false>, 256, 0);
 	return e == hipSuccess && n > 0 ? n : 1;
 }
 
@@ -562,18 +561,17 @@ void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameCo
 	if (chunks <= 0) return;
 	long long blocks = (chunks + 15) / 16; // never more workgroups than 64-pixel groups
 	if (blocks > resident_blocks) blocks = resident_blocks;
-	const bool coarse = sc.coarse_field != nullptr;
+	if (instrumented)
+		hipLaunchKernelGGL(trace_paths<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc_dev, reinterpret_cast<float4*>(accum), dbg,
+						   counters, work_counter);
+	else
 #ifdef BM_PHASE_TIMING
-	DeviceCounters* const plain_counters = counters;
+		hipLaunchKernelGGL(trace_paths<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc_dev, reinterpret_cast<float4*>(accum), nullptr,
+						   counters, work_counter);
 #else
-	DeviceCounters* const plain_counters = nullptr;
+		hipLaunchKernelGGL(trace_paths<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc_dev, reinterpret_cast<float4*>(accum), nullptr,
+						   nullptr, work_counter);
 #endif
-	const dim3 grid(static_cast<unsigned>(blocks)), block(256);
-	float4* const acc4 = reinterpret_cast<float4*>(accum);
-	if (instrumented && coarse) hipLaunchKernelGGL((trace_paths<true, true>), grid, block, 0, stream, sc, fc_dev, acc4, dbg, counters, work_counter);
-	else if (instrumented) hipLaunchKernelGGL((trace_paths<true, false>), grid, block, 0, stream, sc, fc_dev, acc4, dbg, counters, work_counter);
-	else if (coarse) hipLaunchKernelGGL((trace_paths<false, true>), grid, block, 0, stream, sc, fc_dev, acc4, nullptr, plain_counters, work_counter);
-	else hipLaunchKernelGGL((trace_paths<false, false>), grid, block, 0, stream, sc, fc_dev, acc4, nullptr, plain_counters, work_counter);
 }
 
 void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const uint32_t* indices_queue, uint32_t* arena, uint32_t count,

@@ -179,7 +179,6 @@ struct RayState {
 	int last_step;      // packed-cell increment of the last move (0 before the first): which axis it was, see move_axis
 	int last_axis;      // the same as an axis number (-1 before the first move): what trace_k.hip keeps instead of last_step
 	uint32_t field_off;      // byte offset of the ray's octant plane in DeviceScene::cube_field
-	uint32_t field_off_c;    // ... and in DeviceScene::coarse_field (kernels instantiated with COARSE only)
 	uint32_t cube;           // edge of the empty cube ahead of the current cell (its cube_field byte)
 	float distance;     // result
 	bool hit;
@@ -216,22 +215,11 @@ __device__ __forceinline__ int move_axis(int last_step) {
 #define BM_JUMP_MIN 4 // smallest cube edge worth a jump (a jump costs about four single steps)
 #endif
 constexpr uint32_t kCubeNoJump = 0x100u; // RayState::cube flag: tmax is outside the range of jump.h, take single moves
-constexpr uint32_t kCoarseMin = 4u;      // smallest coarse byte that stands in for the fine one (below it the fine field knows more)
-// COARSE: the scene has a coarse level (DeviceScene::coarse_field): one byte per 4x4x4 block, small enough to stay in the L2 of a
-// world whose fine field does not; it is read first and the fine byte only where the block is near a surface.
-template <bool COARSE = false>
 __device__ __forceinline__ int field_lookup(const DeviceScene& sc, RayState& r) {
 	const uint32_t fx = r.p & 0x7FFu, fy = (r.p >> 11) & 0x7FFu, fz = r.p >> 22;
 	// bordered cell coordinate = field - 15 (16-cell bias, one border cell): the three "- 15" are folded into sc.cube_field
 	const uint32_t idx = __umul24(fz, static_cast<uint32_t>(sc.cf_xy)) + (__umul24(fy, static_cast<uint32_t>(sc.cf_x)) + fx) + r.field_off;
-	uint32_t v;
-	if (COARSE) {
-		const uint32_t idc = __umul24(fz >> 2, static_cast<uint32_t>(sc.cc_xy)) + (__umul24(fy >> 2, static_cast<uint32_t>(sc.cc_x)) + (fx >> 2)) + r.field_off_c;
-		v = sc.coarse_field[idc];
-		if (v < kCoarseMin) v = sc.cube_field[idx];
-	} else {
-		v = sc.cube_field[idx];
-	}
+	const uint32_t v = sc.cube_field[idx];
 	const float m = fminf(fminf(r.tx, r.ty), r.tz);
 	// select-style, no short-circuit: a branchy version costs its full instruction count in a divergent wave anyway
 	const bool possible = __float_as_uint(m) - kJumpMinBits < kJumpMaxBits - kJumpMinBits; // jump_possible(): tmax in the range jump.h handles
@@ -245,7 +233,7 @@ __device__ __forceinline__ int field_lookup(const DeviceScene& sc, RayState& r) 
 
 // voxel.cuh:249-258: one Amanatides-Woo move to the next cell, then the new cell's byte.  Select-style (no per-axis branches);
 // `t += mask ? delta : 0` is the reference's `tmax += mask * tdelta` for finite deltas.
-template <bool DBG, bool COARSE = false>
+template <bool DBG>
 __device__ __forceinline__ int field_step(const DeviceScene& sc, RayState& r, Tally& tally) {
 	const float tx = r.tx, ty = r.ty, tz = r.tz;
 	const bool mx = tx < ty && tx < tz;
@@ -259,7 +247,7 @@ __device__ __forceinline__ int field_step(const DeviceScene& sc, RayState& r, Ta
 	r.tx = tx + (mx ? r.dx : 0.f);
 	r.ty = ty + (my ? r.dy : 0.f);
 	r.tz = tz + (mz ? r.dz : 0.f);
-	const int st = field_lookup<COARSE>(sc, r);
+	const int st = field_lookup(sc, r);
 	if (DBG && st != ST_NEED) tally.index_loads++;
 	return st;
 }
@@ -268,7 +256,7 @@ __device__ __forceinline__ int field_step(const DeviceScene& sc, RayState& r, Ta
 // DIR: RayState::d holds the ray direction (the fused kernel); otherwise |direction| is recovered from tdelta with the
 // hardware reciprocal (the queue kernels keep the direction in the queue record, not in the pooled walk state) -- it only
 // feeds a quotient estimate that is corrected exactly (jump.h).
-template <bool DBG, bool DIR = true, bool COARSE = false>
+template <bool DBG, bool DIR = true>
 __device__ __forceinline__ int field_jump(const DeviceScene& sc, RayState& r, Tally& tally) {
 	uint32_t cx, cy, cz;
 	int axis;
@@ -285,7 +273,7 @@ __device__ __forceinline__ int field_jump(const DeviceScene& sc, RayState& r, Ta
 	r.p += static_cast<uint32_t>(__mul24(static_cast<int>(cx), step_x) + __mul24(static_cast<int>(cy), step_y) + __mul24(static_cast<int>(cz), step_z));
 	r.last_step = axis == 0 ? step_x : (axis == 1 ? step_y : step_z); // (only read after a cube exit, where it is the exit axis)
 	r.last_axis = axis;
-	const int st = field_lookup<COARSE>(sc, r);
+	const int st = field_lookup(sc, r);
 	if (DBG) tally.index_loads += cx + cy + cz - (st == ST_NEED ? 1u : 0u); // the cells the reference would have loaded: all but a final one outside the grid
 	return st;
 }
@@ -336,7 +324,7 @@ __device__ __forceinline__ int walk_round(const DeviceScene& sc, RayState& r, in
 
 // voxel.cuh:136-189: clip against the world box, move onto it, set up the Amanatides-Woo state.
 // Returns the lane's next state: ST_OUTER / ST_CAND, or ST_NEED with r.hit = false when the ray misses the box.
-template <bool DBG, bool COARSE = false>
+template <bool DBG>
 __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const f3 dir, RayState& r, Tally& tally) {
 	r.hit = false;
 	r.d = dir;
@@ -393,8 +381,7 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 	// octant of the direction: a zero component never moves, either plane is valid for it
 	const uint32_t oct = (dir.x < 0.f ? 1u : 0u) | (dir.y < 0.f ? 2u : 0u) | (dir.z < 0.f ? 4u : 0u);
 	r.field_off = oct * sc.cf_plane;
-	if (COARSE) r.field_off_c = oct * sc.cc_plane;
-	return field_lookup<COARSE>(sc, r); // inside the grid: never a border cell
+	return field_lookup(sc, r); // inside the grid: never a border cell
 }
 
 // voxel.cuh:200-247: the current cell holds a non-empty brick -- read its index word and resolve it.

@@ -258,22 +258,4 @@ void World::build_cube_field(std::vector<uint8_t>& field, int threads) const {
 	for (auto& th : pool) th.join();
 }
 
-void World::build_coarse_field(const std::vector<uint8_t>& field, std::vector<uint8_t>& coarse) const {
-	const int X = dims.cells + 2, Z = dims.cells_height + 2;
-	const size_t plane = static_cast<size_t>(X) * X * Z;
-	const int CX = dims.cells / 4 + 2, CZ = dims.cells_height / 4 + 2;
-	const size_t cplane = static_cast<size_t>(CX) * CX * CZ;
-	coarse.assign(cplane * 8, 255);
-	for (int o = 0; o < 8; ++o)
-		for (int z = 0; z < Z; ++z)         // bordered coordinates: cell = coordinate - 1, packed-cell field = coordinate + 15
-			for (int y = 0; y < X; ++y) {
-				const uint8_t* row = &field[plane * o + (static_cast<size_t>(z) * X + y) * X];
-				uint8_t* crow = &coarse[cplane * o + (static_cast<size_t>(((z + 15) >> 2) - 3) * CX + (((y + 15) >> 2) - 3)) * CX];
-				for (int x = 0; x < X; ++x) {
-					uint8_t& c = crow[((x + 15) >> 2) - 3];
-					c = std::min(c, row[x]);
-				}
-			}
-}
-
 } // namespace bm

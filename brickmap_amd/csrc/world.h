@@ -59,10 +59,6 @@ public:
 	// cells inside the grid that has c as its near corner and extends towards -x / -y / -z where bit 0 / 1 / 2 of o is
 	// set, +x / +y / +z otherwise; 0 for a cell whose index word is non-zero, 255 for the border cells.
 	void build_cube_field(std::vector<uint8_t>& field, int threads) const;
-	// Coarse level of the cube field (device_types.h DeviceScene::coarse_field): 8 planes of (cells / 4 + 2)^2 * (cells_height / 4 + 2)
-	// bytes, one per 4x4x4 block of cells -- blocks are cut on the packed cell's BIASED coordinates ((x + 16) >> 2), so a block
-	// holds interior cells only or border cells only; byte = the smallest fine byte of the block's cells (255 for a border block).
-	void build_coarse_field(const std::vector<uint8_t>& field, std::vector<uint8_t>& coarse) const;
 
 private:
 	void build_supercell(int sx, int sy, int sz, const float* heights);
