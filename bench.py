@@ -41,13 +41,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# what bounds trace_paths on each workload (profiles/r03_pmc_summary_<workload>.json, profiles/r03_fetch_calibration.txt)
+# what bounds trace_paths on each workload (profiles/r0x_pmc_summary_<workload>.json, profiles/r03_fetch_calibration.txt)
 LIMITER = {
     "config2": "VALU issue: the vector pipes are busy for >= 85 % of the launch with ~20 of 64 lanes active per instruction; the scene (93 MiB) stays in L2 / Infinity Cache",
     "config3": "VALU issue, with 0.6 G L2 sector misses per launch (TCC hit 61 %)",
     "config5": "two limits at once: 41.5 G single-sector (64 B) read requests/s = 0.86 of the 48 G/s the fabric sustains for random sectors (3.1 TB/s, not the 8 TB/s byte peak), and VALU issue (vector pipes full at ~18 of 64 lanes per instruction)",
 }
-PROFILE_ROUND = "r03"  # profiles/<round>_pmc_summary*.json is where roofline.traffic comes from
+PROFILE_ROUNDS = ("r04", "r03")  # profiles/<round>_pmc_summary_<workload>.json is where roofline.traffic comes from (newest first; the kernel is unchanged since round 2)
 
 
 def workload(name):
@@ -77,9 +77,12 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the fixed job (frame at --multi-gpu-spp samples) over N ranks; weak = N x spp samples in total")
     ap.add_argument("--multi-gpu-spp", type=int, default=8, help="samples per pixel of the strong-scaled job (N > 1)")
-    ap.add_argument("--pipeline", type=int, default=1,
+    ap.add_argument("--pipeline", type=int, default=None,
                     help="resident scenes: consecutive steps are issued on this many alternating HIP streams (one accumulation buffer each), "
-                         "so that the next frame's workgroups start while the previous frame drains; 1 = one stream")
+                         "so that the next frame's workgroups start while the previous frame drains; 1 = one stream.  Default: 1 for "
+                         "--gpus 1 (the headline is one kernel at a time, so that its own duration is what the roofline prices), 2 for "
+                         "--gpus N > 1 (every rank overlaps its consecutive shard steps: a 1/N shard pays the end-of-frame drain of a "
+                         "whole launch, DESIGN.md 6)")
     ap.add_argument("--verify", action="store_true",
                     help="N > 1: after the timed region rank 0 renders every step unsharded and compares it with the gathered / reduced frame")
     ap.add_argument("--no-extras", action="store_true",
@@ -91,6 +94,8 @@ def main():
                     help="fused = one persistent kernel tracing complete paths (the product's default); wavefront = the "
                          "reference's own queue schedule, one segment of every path in flight per step (N = 1 only)")
     args = ap.parse_args()
+    if args.pipeline is None:
+        args.pipeline = 1 if (args.gpus == 1 and os.environ.get("BM_BENCH_FORCE_DIST") != "1") else 2
 
     import numpy as np
     import torch
@@ -374,10 +379,14 @@ def main():
     if not multi and args.workload == "config2" and not streaming and not args.no_extras and same_job is not None and "ms_per_step" in same_job:
         try:
             shard_pred = {"job": same_job["workload"], "unsharded_ms_per_step": same_job["ms_per_step"], "shard_kernel_ms": {}, "shard_ms_per_step": {},
-                          "predicted_speedup": {}, "note": "rank 0's shard of the job on this GPU, one stream, no gather: value(N) / value(1 GPU, same job) "
-                          "should come out near predicted_speedup[N]"}
+                          "predicted_speedup": {}, "note": "rank 0's shard of the job on this GPU, no gather.  --gpus N runs every rank's steps on two alternating streams by default: "
+                          "value(N) / (the unsharded job's rate on one GPU) should come out near predicted_speedup_two_streams[N] "
+                          "(predicted_speedup[N] with --pipeline 1)"}
+            two = pick_streams(2)
+            shard_pred["shard_ms_per_step_two_streams"], shard_pred["predicted_speedup_two_streams"] = {}, {}
             for n_ranks in (2, 4, 8):
                 st = bm.State(W, H, device=local_rank, band_rows=band, shard_rank=0, shard_count=n_ranks)
+                bufs = [st.blit_buffer, torch.zeros_like(st.blit_buffer)]
                 ps = lambda i: bm.FrameParams(W, H, spp=job_spp, sample_base=7000 + i * job_spp, max_bounces=max_bounces, flags=bm.BM_FLAG_SAMPLE_ITEMS,
                                               band_rows=band, shard_rank=0, shard_count=n_ranks)
                 ns = 6
@@ -392,7 +401,16 @@ def main():
                 shard_pred["shard_ms_per_step"][str(n_ranks)] = round(ss, 4)
                 shard_pred["shard_kernel_ms"][str(n_ranks)] = round(float(np.mean(scene.render_times(ns))), 4)
                 shard_pred["predicted_speedup"][str(n_ranks)] = round(same_job["ms_per_step"] / ss, 3)
-                del st
+                for rep in range(2):  # (the first repetition warms the second stream up)
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    for i in range(2 * ns):
+                        scene.render(cam, ps(10 + i), bufs[i % 2], stream=two[i % 2].cuda_stream)
+                    torch.cuda.synchronize()
+                    s2 = (time.perf_counter() - ts) / (2 * ns) * 1e3
+                shard_pred["shard_ms_per_step_two_streams"][str(n_ranks)] = round(s2, 4)
+                shard_pred["predicted_speedup_two_streams"][str(n_ranks)] = round(same_job["ms_per_step"] / s2, 3)
+                del st, bufs
         except Exception as e:  # noqa: BLE001 -- an extra: must not cost the headline measurement
             torch.cuda.synchronize()
             shard_pred = {"error": repr(e)}
@@ -626,12 +644,20 @@ def cpu_baseline(W, H, max_bounces, G, cam):
     }
 
 
+def pmc_summary_path(workload):
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary_{workload}.json")
+        if os.path.exists(path):
+            return path
+    return None
+
+
 def limiter_of(workload):
     """{"limiter": what bounds the kernel on this workload, "limiter_source": the committed counter passes the statement rests on}.
     The statement is about the DEFAULT build and schedule as profiled in `limiter_source` (not re-derived by this run); it is
     omitted when no PMC summary of the workload is committed (config 1, config 4: config 3's kernel on another frame size)."""
-    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_summary_{workload}.json")
-    if workload not in LIMITER or not os.path.exists(path) or os.environ.get("BM_SCHEDULE"):
+    path = pmc_summary_path(workload)
+    if workload not in LIMITER or path is None or os.environ.get("BM_SCHEDULE"):
         return {"limiter": None, "limiter_source": None}
     return {"limiter": LIMITER[workload], "limiter_source": f"profiles/{os.path.basename(path)} + DESIGN.md 5 (default build, default schedule)"}
 
@@ -643,8 +669,9 @@ def pmc_traffic(workload):
     FETCH_SIZE = read requests x 64 B: the guide's x2 applies to full-line coalesced streams only; every read of this
     kernel is a single 64-byte sector request, for which FETCH_SIZE is exact (profiles/r03_fetch_calibration.txt, measured
     with tools/ubench/fetch_calib.hip on 1-byte / 4-byte / 64-byte gathers) -- factor 1.0.  Infinity-Cache hits are included."""
-    name = f"pmc_summary_{workload}.json"
-    path = os.path.join(ROOT, "profiles", PROFILE_ROUND + "_" + name)
+    path = pmc_summary_path(workload)
+    if path is None:
+        return {"traffic": None, "traffic_source": None}
     try:
         with open(path) as f:
             d = json.load(f)

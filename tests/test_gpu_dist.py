@@ -102,7 +102,7 @@ def test_default_bench_line_schema():
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     assert "reference-equivalent" in rf["achieved_is"] and "VALU" in rf["limiter"] and "pmc_summary_config2" in rf["limiter_source"]
     assert rf["kernel_ms_avg"] <= out["ms_per_step"] * 1.05
-    assert rf["traffic"] and "r03_pmc_summary_config2.json" in rf["traffic_source"]
+    assert rf["traffic"] and "_pmc_summary_config2.json" in rf["traffic_source"]
     assert out["multi_gpu_job_on_one_gpu"]["ms_per_step"] > 0 and out["north_star_4spp"]["roofline_frac"] > 0 and out["pipelined"]["ms_per_step"] > 0
     # the scaling prediction the first real multi-GPU run is checked against: rank 0's shard of the 8-spp job at N = 2 / 4 / 8
     pred = out["multi_gpu_prediction"]

@@ -46,6 +46,7 @@ struct CandRec { uint8_t steps, hit; };
 static std::vector<RayRec> g_rays;
 static std::vector<CandRec> g_cands;
 static std::vector<uint32_t> g_path_first, g_path_count; // per pixel
+static std::vector<uint32_t> g_tile_perm; // hand-out position -> 16x16-pixel tile (order=...: tiles sorted by the cost of their paths)
 static void ray_probe(unsigned pixel, int, int kind, const float* o, const float* d) {
 	RayRec r;
 	memcpy(r.o, o, 12); memcpy(r.d, d, 12);
@@ -242,7 +243,8 @@ struct Sim {
 					const uint32_t ticket = item1 / 4u, part = item1 % 4u;
 					const uint32_t chunk = ((ticket >> 2) * 8u + counter_now) * 4u + (ticket & 3u);
 					if (item < my_tickets && chunk < total_chunks) {
-						const uint32_t tile = chunk >> 4, k = chunk & 15u;
+						const uint32_t tile0 = chunk >> 4, k = chunk & 15u;
+						const uint32_t tile = g_tile_perm.empty() ? tile0 : g_tile_perm[tile0];
 						const int tile_x = int(tile % (uint32_t)tiles_x), tile_y = int(tile / (uint32_t)tiles_x);
 						const int cx = int((k & 1u) | ((k >> 1) & 2u)), cy = int(((k >> 1) & 1u) | ((k >> 2) & 2u));
 						const uint32_t q = part * 4u + ((uint32_t)rank % 4u);
@@ -433,6 +435,23 @@ int main(int argc, char** argv) {
 				uint8_t& c = g_coarse[o * g_cplane + (size_t(((z + 16) >> 2) - 3) * g_cb + (((y + 16) >> 2) - 3)) * g_cb + (((x + 16) >> 2) - 3)];
 				c = std::min<uint8_t>(c, (uint8_t)g_w.F(o, x, y, z));
 			}
+	}
+	if (const char* ord = getenv("BM_SIM_ORDER")) {
+		// hand-out order experiments: "lpt" = tiles by the number of rays of their paths, most expensive first (a list scheduler's
+		// order); "skylast" = the normal order, but tiles whose every path is a single ray (sky) go to the end; "bottomup"
+		const int tx = (W + 15) / 16, ty = (H + 15) / 16;
+		std::vector<std::pair<double, uint32_t>> cost(size_t(tx) * ty);
+		for (int t = 0; t < tx * ty; ++t) {
+			double c = 0; int n = 0;
+			for (int y = (t / tx) * 16; y < std::min(H, (t / tx) * 16 + 16); ++y) for (int x = (t % tx) * 16; x < std::min(W, (t % tx) * 16 + 16); ++x) { c += g_path_count[size_t(y) * W + x]; n++; }
+			cost[t] = {n ? c / n : 0.0, uint32_t(t)};
+		}
+		g_tile_perm.resize(cost.size());
+		if (!strcmp(ord, "lpt")) { std::stable_sort(cost.begin(), cost.end(), [](auto& a, auto& b) { return a.first > b.first; }); for (size_t i = 0; i < cost.size(); ++i) g_tile_perm[i] = cost[i].second; }
+		else if (!strcmp(ord, "skylast")) { size_t k = 0; for (auto& c : cost) if (c.first > 1.0) g_tile_perm[k++] = c.second; for (auto& c : cost) if (c.first <= 1.0) g_tile_perm[k++] = c.second; }
+		else if (!strcmp(ord, "bottomup")) { for (size_t i = 0; i < cost.size(); ++i) g_tile_perm[i] = uint32_t(cost.size() - 1 - i); }
+		else if (!strcmp(ord, "skyfirst_terrain_lpt")) { size_t k = 0; for (auto& c : cost) if (c.first <= 1.0) g_tile_perm[k++] = c.second; std::vector<std::pair<double, uint32_t>> rest; for (auto& c : cost) if (c.first > 1.0) rest.push_back(c); std::stable_sort(rest.begin(), rest.end(), [](auto& a, auto& b) { return a.first > b.first; }); for (auto& c : rest) g_tile_perm[k++] = c.second; }
+		else g_tile_perm.clear();
 	}
 	auto run = [&](const Params& P) {
 		Sim sim; sim.P = P; sim.P.nwaves = P.W * (1024 / (P.tiles > 1 ? P.tiles : 1)); sim.W_img = W; sim.H_img = H; sim.tiles_x = (W + 15) / 16; sim.tiles_y = (H + 15) / 16;
