@@ -125,5 +125,8 @@ def test_bench_helpers_run_without_a_gpu():
     assert 1 <= physical <= logical and 1 <= b.cpu_quota() <= logical and isinstance(model, str)
     for wl in ("config2", "config3", "config5"):
         t = b.pmc_traffic(wl)
-        assert t["traffic"] and t["traffic"] > 0 and f"{b.PROFILE_ROUND}_pmc_summary_{wl}.json" in t["traffic_source"]
+        assert t["traffic"] and t["traffic"] > 0 and f"{b.PROFILE_ROUNDS[0]}_pmc_summary_{wl}.json" in t["traffic_source"]
+        lim = b.limiter_of(wl)
+        assert lim["limiter"] and f"_pmc_summary_{wl}.json" in lim["limiter_source"]
+    assert b.limiter_of("config1") == {"limiter": None, "limiter_source": None}  # no committed PMC summary: no claim
     assert b.pmc_traffic("no-such-workload") == {"traffic": None, "traffic_source": None}
