@@ -18,7 +18,9 @@ MULTI_GPU_SPP = 8 samples per pixel, cut into interleaved 16-row bands (band b b
 all 8 samples of its rows into a packed float4 buffer (work items = (4x4 chunk, sample) pairs, BM_FLAG_SAMPLE_ITEMS, so
 the persistent waves stay fed on 1/N of the pixels), and the packed bands are gathered to rank 0 over RCCL/xGMI
 (brickmap_amd/dist.py FrameGatherer: grouped send/recv, 33 MB / N per peer per step).  The gather of step i overlaps the
-tracing of step i+1; every gather, including the last, completes inside the timed region.  Rates are per nominal ray,
+tracing of step i+1; every gather, including the last, completes inside the timed region.  For N > 1 every rank issues its
+consecutive steps on two alternating streams by default (`--pipeline 2`: a 1/N shard pays the end-of-frame drain of a whole
+launch; overlapping the next step hides it -- DESIGN.md 6); the exchange itself is the C-ABI's bm_gather_frame (csrc/comm.hip).  Rates are per nominal ray,
 but the N = 1 line is a DIFFERENT work shape (1 spp, pixel items; its end-of-frame drain is not amortised over samples,
 and coherent neighbouring samples run ~20 % faster per ray), so a scaling efficiency must not be computed against it:
 every N > 1 line carries `same_job_single_gpu` (rank 0 renders the line's own 8-spp job unsharded, untimed) and the
@@ -446,6 +448,8 @@ def main():
                          f"{world} x interleaved {band}-row bands, every rank all {spp_rank} samples of its rows ((chunk, sample) work items) "
                          f"+ RCCL gather of the packed bands to rank 0, one gather in flight" if by_rows else
                          f"{world} x sample shards (every rank the full frame, {spp_rank} of the {spp_total} samples) + one RCCL sum-reduce to rank 0 after the last step"),
+            "exchange": (None if not multi else ("C-ABI bm_gather_frame / bm_reduce_frame over RCCL (csrc/comm.hip)" if getattr(gatherer or reducer, "comm", None) is not None
+                                                     else "torch.distributed gather / reduce")),
             "camera": {"position": list(cam.position), "angles": [0.8, -0.5]},
             "world_build_s": round(build_s, 2),
         },

@@ -102,6 +102,29 @@ class Comm:
             pass
 
 
+def _make_comm(device_index, group):
+    """The C-ABI communicator for a process group, checked before it is relied on: every rank runs bm_comm_selftest (a grouped
+    send / receive round the ring of ranks + an all-reduce, data verified) and the ranks agree on the outcome -- if the
+    communicator cannot be made or the check fails on ANY rank, all of them fall back to torch.distributed's exchange."""
+    import torch
+    import torch.distributed as dist
+    comm, ok = None, 1
+    try:
+        comm = Comm.from_process_group(device_index, group)
+        comm.selftest()
+    except Exception as e:  # noqa: BLE001 -- anything at all: the render must not depend on it
+        ok = 0
+        import sys
+        print(f"brickmap_amd.dist: C-ABI RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
+    t = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", device_index))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    if int(t.item()) != 1:
+        if comm is not None:
+            comm.close()
+        return None
+    return comm
+
+
 def _use_capi(collective, group, device):
     """The C-ABI exchange serves RCCL groups with device frames; gloo (CPU tests) and BM_DIST_TORCH=1 keep torch.distributed's."""
     import torch
@@ -203,7 +226,8 @@ class FrameGatherer:
         # the exchange behind the C-ABI (bm_gather_frame) on a side stream: it runs behind the snapshot and beside the next frame
         self.comm = None
         if _use_capi(self.collective, group, self.out_device) and channels == 4 and dtype == torch.float32:
-            self.comm = Comm.from_process_group(self.out_device.index if self.out_device.index is not None else torch.cuda.current_device(), group)
+            self.comm = _make_comm(self.out_device.index if self.out_device.index is not None else torch.cuda.current_device(), group)
+        if self.comm is not None:
             self.side = torch.cuda.Stream(device=self.out_device)
             self.snap = torch.cuda.Event()
             self.recv_all = self.recv = self.index = None  # (the root's receive buffer belongs to the communicator)
@@ -270,7 +294,8 @@ class FrameReducer:
         self.local = None
         self.comm = None
         if _use_capi(self.collective, group, self.out_device) and (dtype or torch.float32) == torch.float32:
-            self.comm = Comm.from_process_group(self.out_device.index if self.out_device.index is not None else torch.cuda.current_device(), group)
+            self.comm = _make_comm(self.out_device.index if self.out_device.index is not None else torch.cuda.current_device(), group)
+        if self.comm is not None:
             self.side = torch.cuda.Stream(device=self.out_device)
             self.snap = torch.cuda.Event()
             self.pending = False

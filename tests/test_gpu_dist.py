@@ -65,7 +65,7 @@ def test_root_assembly_kernel_with_three_ranks_on_one_gpu():
     scene.close()
 
 
-@pytest.mark.parametrize("extra", [[], ["--pipeline", "2"], ["--decomposition", "samples"]])
+@pytest.mark.parametrize("extra", [[], ["--pipeline", "1"], ["--decomposition", "samples"]])
 def test_bench_multi_gpu_code_path_on_nccl_with_one_rank(extra):
     """bench.py's N > 1 path (RCCL process group, row-band shard with (chunk, sample) items, pipelined device gather,
     barrier, max-over-ranks all_reduce, --verify, same_job_single_gpu) with WORLD_SIZE = 1."""

@@ -986,7 +986,7 @@ def test_sample_items_digest_matches_oracle(bm, orc, torch_cuda, scene256, world
 
 def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
     """`bench.py --gpus 2` end to end -- row-band shards with (chunk, sample) work items, pipelined gather to rank 0 (the driver's
-    command line, then with every rank's frames overlapping on two streams, then the sample decomposition),
+    command line: every rank's frames overlap on two streams; then on one stream; then the sample decomposition),
     the gathered / reduced frames compared with one GPU rendering everything (--verify),
     max-over-ranks timing, one JSON line -- with both ranks on this GPU and gloo instead of RCCL (BM_BENCH_SHARE_GPU=1).
     The 8-GPU run itself is the driver's; this pins the code path it takes."""
@@ -996,7 +996,7 @@ def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
     import sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ([], ["--pipeline", "2"], ["--pipeline", "2", "--decomposition", "samples"]):
+    for extra in ([], ["--pipeline", "1"], ["--decomposition", "samples"]):  # (N > 1 runs every rank's steps on two streams by default)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", "config1", "--verify"] + extra
         env = dict(os.environ, BM_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
@@ -1008,7 +1008,7 @@ def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
         assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "strong"
         assert out["config"]["spp_per_step"] == 8 and "roofline" in out and "cpu_baseline" not in out
         assert out["verified_against_single_gpu"]["frames"] == 5 and out["verified_against_single_gpu"]["max_rel_err"] < 1e-5
-        assert ("pipeline" in out) == ("--pipeline" in extra) and out.get("pipeline", {"streams": 2})["streams"] == 2
+        assert ("pipeline" in out) == ("--pipeline" not in extra) and out.get("pipeline", {"streams": 2})["streams"] == 2
         port += 1
 
 
