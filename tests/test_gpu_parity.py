@@ -342,6 +342,38 @@ def test_request_ring_overflow(bm, orc, torch_cuda):
     scene.close()
 
 
+def test_request_ring_overflow_in_overlapped_mode(bm, orc, torch_cuda):
+    """The overlapped mode's snapshot kernel copies min(count, capacity) entries of a ring whose counter ran past its capacity
+    (the device counter keeps counting, kernel.cu:409 / Scene.cpp:203 clamp it): every call services at most `capacity` bricks,
+    none twice, and the scene still converges to the resident image."""
+    G, W, H = 256, 96, 64
+    scene = bm.Scene(G, G, device=0)
+    scene.set_queue_capacity(64)
+    scene.generate()
+    scene.set_streaming_mode(True)
+    cam, _ = cameras(bm, orc, G)
+    p = bm.FrameParams(W, H, spp=1, max_bounces=3)
+    total, batches, idle = 0, [], 0
+    for _ in range(400):
+        gpu_render(bm, torch_cuda, scene, cam, p, want_dbg=False)
+        n = scene.process_load_queue()
+        assert 0 <= n <= 64
+        total += n
+        batches.append(n)
+        idle = idle + 1 if n == 0 else 0
+        if idle >= 3:  # (a request is serviced two calls after the frame that raised it)
+            break
+    else:
+        pytest.fail("overlapped streaming with a 64-entry ring did not reach a steady state")
+    assert max(batches) == 64 and total == scene.info()["resident_bricks"] > 256
+    acc_s, dbg_s = gpu_render(bm, torch_cuda, scene, cam, p)
+    ref = bm.Scene(G, G, device=0).generate().preload_all()
+    acc_r, dbg_r = gpu_render(bm, torch_cuda, ref, cam, p)
+    assert np.array_equal(dbg_s, dbg_r) and np.array_equal(acc_s, acc_r)
+    ref.close()
+    scene.close()
+
+
 def test_sharded_equals_unsharded_and_accumulation(bm, orc, torch_cuda, scene256):
     torch = torch_cuda
     cam, _ = cameras(bm, orc, 256)

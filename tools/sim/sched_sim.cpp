@@ -79,6 +79,8 @@ struct Params {
 	int minfill = 0; // pool mode: a wave that finds fewer lanes than this for every pass type sleeps while other waves hold slots
 	double beta = 0; // > 0: staged shutdown -- slot layer k is refilled only while the pixels left exceed k * beta * (lanes of the machine)
 	int nwaves = 0;
+	int split = 0; // 1: prepass launch (primary rays only, no shading), 2: the path launch that starts from the prepass's hit records
+	double cGen = 320, cRec = 40; // prepass: primary ray + set-up; writing the hit record
 	int rep = 1; // every pixel is handed out `rep` times (a steady-state / multi-sample frame: the drain is amortised)
 	double wB = 1.0, wC = 1.0; // policy 2: run the pass type with the largest (lanes * weight); the walk has weight 1
 };
@@ -253,6 +255,8 @@ struct Sim {
 							const uint32_t p = (uint32_t)y * W_img + x;
 							if (g_path_count[p]) { // (pixels outside the sampled tiles have no path: the lane stays idle)
 								s.st = S_NEED; s.next_ray = g_path_first[p]; s.ray_end = s.next_ray + g_path_count[p]; s.ray = nullptr;
+								if (P.split == 1) s.ray_end = s.next_ray + 1;   // prepass: the primary ray only
+								if (P.split == 2) { s.next_ray += 1; }          // path launch: the primary ray has been traced
 								if (P.pool) claim(&s);
 							}
 						}
@@ -320,7 +324,7 @@ struct Sim {
 				}
 			}
 			st.runs[3]++; st.lanes[3] += n;
-			add(3, P.cC + P.ovC, 1);
+			add(3, (P.split == 1 ? P.cGen + P.cRec : P.cC + (P.split == 2 ? 90 : 0)) + P.ovC, 1);
 		} else if (phase == 1) {
 			int n = 0, longest = 0;
 			for (int l = 0; l < 64; ++l) {
@@ -386,7 +390,7 @@ int main(int argc, char** argv) {
 	std::map<std::string, double*> dk = {{"qB", &P.qB}, {"qC", &P.qC}, {"lat", &P.lat}, {"cpi", &P.cpi}, {"ovJ", &P.ovJ}, {"ovS", &P.ovS}, {"ovB", &P.ovB}, {"ovC", &P.ovC},
 										 {"sched", &P.schedMul}, {"cJ", &P.cJ}, {"cS", &P.cS}, {"cB", &P.cB}, {"cBstep", &P.cBstep}, {"cC", &P.cC}, {"cSched", &P.cSched}, {"cRefill", &P.cRefill}, {"wB", &P.wB}, {"wC", &P.wC}, {"beta", &P.beta}};
 	std::map<std::string, int*> ik = {{"K", &P.K}, {"W", &P.W}, {"refillmin", &P.refill_min}, {"tiles", &P.tiles}, {"policy", &P.policy}, {"jumpmin", &P.jump_min},
-									  {"jumppasses", &P.jump_passes}, {"steps", &P.steps_per_round}, {"rep", &P.rep}, {"pool", &P.pool}, {"minfill", &P.minfill}};
+									  {"jumppasses", &P.jump_passes}, {"steps", &P.steps_per_round}, {"rep", &P.rep}, {"pool", &P.pool}, {"minfill", &P.minfill}, {"split", &P.split}};
 	std::vector<std::string> sweeps;
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i];
