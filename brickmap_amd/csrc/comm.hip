@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -48,8 +49,11 @@ Rccl* rccl() {
 	static bool tried = false;
 	if (!tried) {
 		tried = true;
-		const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+		// BM_RCCL_LIBRARY names a specific build of the library (a site's own RCCL; the tests' host-staged stand-in that lets
+		// several ranks share one GPU, tests/fake_rccl.cpp)
+		const char* names[] = {std::getenv("BM_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
 		for (const char* n : names) {
+			if (!n || !*n) continue;
 			api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
 			if (api.lib) break;
 		}

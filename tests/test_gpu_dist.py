@@ -65,6 +65,35 @@ def test_root_assembly_kernel_with_three_ranks_on_one_gpu():
     scene.close()
 
 
+@pytest.mark.parametrize("world,root", [(2, 0), (3, 1)])
+def test_cabi_exchange_with_several_ranks_on_one_gpu(world, root, tmp_path):
+    """bm_comm_create / bm_comm_selftest / bm_gather_frame / bm_reduce_frame / bm_comm_barrier with 2 and 3 ranks -- unequal
+    shards, a root other than 0, two frames through one communicator -- as separate processes that share GPU 0.  Real RCCL
+    refuses two ranks on one device, so the ten entry points csrc/comm.hip binds are served by a host-staged stand-in
+    (tests/fake_rccl.cpp via BM_RCCL_LIBRARY): this pins the per-rank counts, the offsets into the root's stacked buffer and the
+    assembly end to end; RCCL's own transport stays for a multi-GPU node."""
+    fake = tmp_path / "libfake_rccl.so"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-Wno-unused-result", "-x", "hip", "--offload-arch=gfx950",
+                           os.path.join(ROOT, "tests", "fake_rccl.cpp"), "-o", str(fake), "-lrt", "-lpthread"])
+    env = dict(os.environ, BM_RCCL_LIBRARY=str(fake), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    id_file = str(tmp_path / "id")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_fake_rccl_worker.py"), str(r), str(world), id_file, str(root)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=ROOT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"FAKE_RCCL_RANK_OK {r}" in out, f"rank {r}:\n" + out[-3000:]
+
+
 @pytest.mark.parametrize("extra", [[], ["--pipeline", "1"], ["--decomposition", "samples"]])
 def test_bench_multi_gpu_code_path_on_nccl_with_one_rank(extra):
     """bench.py's N > 1 path (RCCL process group, row-band shard with (chunk, sample) items, pipelined device gather,
