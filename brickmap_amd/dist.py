@@ -116,7 +116,7 @@ def _make_comm(device_index, group):
         ok = 0
         import sys
         print(f"brickmap_amd.dist: C-ABI RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
-    t = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", device_index))
+    t = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", device_index) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     if int(t.item()) != 1:
         if comm is not None:
@@ -129,8 +129,10 @@ def _use_capi(collective, group, device):
     """The C-ABI exchange serves RCCL groups with device frames; gloo (CPU tests) and BM_DIST_TORCH=1 keep torch.distributed's."""
     import torch
     import torch.distributed as dist
-    return (collective and dist.is_initialized() and dist.get_backend(group) == "nccl" and torch.device(device).type == "cuda"
-            and os.environ.get("BM_DIST_TORCH", "0") != "1")
+    if not (collective and dist.is_initialized() and torch.device(device).type == "cuda") or os.environ.get("BM_DIST_TORCH", "0") == "1":
+        return False
+    # BM_DIST_CAPI=1: also on a gloo group (the tests' shared-GPU runs, with BM_RCCL_LIBRARY naming a stand-in transport)
+    return dist.get_backend(group) == "nccl" or os.environ.get("BM_DIST_CAPI", "0") == "1"
 
 
 def shard_rows(height, band_rows, rank, world):
@@ -210,27 +212,28 @@ class FrameGatherer:
         self.counts = [len(shard_rows(height, band_rows, r, self.world)) for r in range(self.world)]
         self.out_device = torch.device(device) if device is not None else torch.device("cpu")
         dtype = dtype or torch.float32
+        # the exchange behind the C-ABI (bm_gather_frame) where it applies: it runs on a side stream, behind a snapshot of the packed
+        # rows and beside the next frame.  (Made first: the buffers below live on the device with it, on the host for gloo.)
+        self.comm = None
+        if _use_capi(self.collective, group, self.out_device) and channels == 4 and dtype == torch.float32:
+            self.comm = _make_comm(self.out_device.index if self.out_device.index is not None else torch.cuda.current_device(), group)
         # gloo (CPU tests / single-GPU smoke runs) has no device gather: stage through host memory there
-        self.stage_on_cpu = self.collective and dist.get_backend(group) == "gloo"
+        self.stage_on_cpu = self.collective and self.comm is None and dist.get_backend(group) == "gloo"
         buf_device = torch.device("cpu") if self.stage_on_cpu else self.out_device
         shape = (max(self.counts), width, channels)
         self.send = torch.zeros(shape, dtype=dtype, device=buf_device)
         root = self.rank == dst
-        self.recv_all = torch.empty((self.world,) + shape, dtype=dtype, device=buf_device) if root else None
-        self.recv = [self.recv_all[r] for r in range(self.world)] if root else None
-        self.index = torch.as_tensor(assembly_index(height, band_rows, self.world), device=buf_device, dtype=torch.long) if root else None
+        torch_path = self.comm is None  # (with the C-ABI exchange the root's receive buffer belongs to the communicator)
+        self.recv_all = torch.empty((self.world,) + shape, dtype=dtype, device=buf_device) if root and torch_path else None
+        self.recv = [self.recv_all[r] for r in range(self.world)] if root and torch_path else None
+        self.index = torch.as_tensor(assembly_index(height, band_rows, self.world), device=buf_device, dtype=torch.long) if root and torch_path else None
         self.out = torch.empty((height, width, channels), dtype=dtype, device=buf_device) if root else None
         self.work = None
         self.local = None
         self.width = width
-        # the exchange behind the C-ABI (bm_gather_frame) on a side stream: it runs behind the snapshot and beside the next frame
-        self.comm = None
-        if _use_capi(self.collective, group, self.out_device) and channels == 4 and dtype == torch.float32:
-            self.comm = _make_comm(self.out_device.index if self.out_device.index is not None else torch.cuda.current_device(), group)
         if self.comm is not None:
             self.side = torch.cuda.Stream(device=self.out_device)
             self.snap = torch.cuda.Event()
-            self.recv_all = self.recv = self.index = None  # (the root's receive buffer belongs to the communicator)
             self.pending = False
 
     def start(self, local):
@@ -286,15 +289,15 @@ class FrameReducer:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.collective = self.world > 1 or (force_collective and dist.is_initialized())  # see FrameGatherer
         self.out_device = torch.device(device) if device is not None else torch.device("cpu")
+        self.comm = None
+        if _use_capi(self.collective, group, self.out_device) and (dtype or torch.float32) == torch.float32:
+            self.comm = _make_comm(self.out_device.index if self.out_device.index is not None else torch.cuda.current_device(), group)
         # gloo (CPU tests / single-GPU smoke runs) reduces host tensors: stage through host memory there
-        self.stage_on_cpu = self.collective and dist.get_backend(group) == "gloo"
+        self.stage_on_cpu = self.collective and self.comm is None and dist.get_backend(group) == "gloo"
         buf_device = torch.device("cpu") if self.stage_on_cpu else self.out_device
         self.buf = torch.zeros((height, width, channels), dtype=dtype or torch.float32, device=buf_device)
         self.work = None
         self.local = None
-        self.comm = None
-        if _use_capi(self.collective, group, self.out_device) and (dtype or torch.float32) == torch.float32:
-            self.comm = _make_comm(self.out_device.index if self.out_device.index is not None else torch.cuda.current_device(), group)
         if self.comm is not None:
             self.side = torch.cuda.Stream(device=self.out_device)
             self.snap = torch.cuda.Event()

@@ -34,3 +34,13 @@ def world256(orc):
     w = orc.World(256, 256)
     w.reset_device(True)
     return w
+
+
+def build_fake_rccl(directory):
+    """tests/fake_rccl.cpp -> <directory>/libfake_rccl.so: the host-staged stand-in for the RCCL entry points csrc/comm.hip binds
+    (BM_RCCL_LIBRARY), which lets several ranks share one GPU in the multi-rank tests of the C-ABI exchange."""
+    import subprocess
+    out = os.path.join(str(directory), "libfake_rccl.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-Wno-unused-result",
+                           "-x", "hip", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "fake_rccl.cpp"), "-o", out, "-lrt", "-lpthread"])
+    return out

@@ -72,9 +72,8 @@ def test_cabi_exchange_with_several_ranks_on_one_gpu(world, root, tmp_path):
     refuses two ranks on one device, so the ten entry points csrc/comm.hip binds are served by a host-staged stand-in
     (tests/fake_rccl.cpp via BM_RCCL_LIBRARY): this pins the per-rank counts, the offsets into the root's stacked buffer and the
     assembly end to end; RCCL's own transport stays for a multi-GPU node."""
-    fake = tmp_path / "libfake_rccl.so"
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-Wno-unused-result", "-x", "hip", "--offload-arch=gfx950",
-                           os.path.join(ROOT, "tests", "fake_rccl.cpp"), "-o", str(fake), "-lrt", "-lpthread"])
+    from conftest import build_fake_rccl
+    fake = build_fake_rccl(tmp_path)
     env = dict(os.environ, BM_RCCL_LIBRARY=str(fake), HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)

@@ -1016,7 +1016,7 @@ def test_sample_items_digest_matches_oracle(bm, orc, torch_cuda, scene256, world
             assert_radiance(b, oacc[mine])
 
 
-def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
+def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda, tmp_path):
     """`bench.py --gpus 2` end to end -- row-band shards with (chunk, sample) work items, pipelined gather to rank 0 (the driver's
     command line: every rank's frames overlap on two streams; then on one stream; then the sample decomposition),
     the gathered / reduced frames compared with one GPU rendering everything (--verify),
@@ -1028,10 +1028,15 @@ def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
     import sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ([], ["--pipeline", "1"], ["--decomposition", "samples"]):  # (N > 1 runs every rank's steps on two streams by default)
+    from conftest import build_fake_rccl
+    fake = build_fake_rccl(tmp_path)
+    # the last two runs take the C-ABI exchange (bm_gather_frame / bm_reduce_frame, what an RCCL group uses) over the stand-in transport
+    for extra, capi in (([], False), (["--pipeline", "1"], False), (["--decomposition", "samples"], False), ([], True), (["--decomposition", "samples"], True)):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", "config1", "--verify"] + extra
         env = dict(os.environ, BM_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
+        if capi:
+            env.update(BM_DIST_CAPI="1", BM_RCCL_LIBRARY=fake)
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -1041,6 +1046,7 @@ def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda):
         assert out["config"]["spp_per_step"] == 8 and "roofline" in out and "cpu_baseline" not in out
         assert out["verified_against_single_gpu"]["frames"] == 5 and out["verified_against_single_gpu"]["max_rel_err"] < 1e-5
         assert ("pipeline" in out) == ("--pipeline" not in extra) and out.get("pipeline", {"streams": 2})["streams"] == 2
+        assert ("C-ABI" in out["config"]["exchange"]) == capi
         port += 1
 
 
