@@ -190,18 +190,22 @@ int bm_gather_frame(bm_comm* c, const float* packed_dev, float* frame_dev, int h
 		}
 	}
 	if (c->world > 1) {
+		// (an error inside the group must not leave RCCL in group mode: the group is always closed, the first error is reported)
 		BM_NCCL(R->GroupStart());
+		ncclResult_t first = ncclSuccess;
 		if (c->rank == root) {
-			for (int r = 0; r < c->world; ++r) {
+			for (int r = 0; r < c->world && first == ncclSuccess; ++r) {
 				if (r == root) continue;
 				const size_t count = static_cast<size_t>(bm::shard_rows(height, band_rows, r, c->world)) * row_floats;
-				if (count) BM_NCCL(R->Recv(c->stacked + static_cast<size_t>(r) * max_rows * row_floats, count, ncclFloat, r, c->comm, stream));
+				if (count) first = R->Recv(c->stacked + static_cast<size_t>(r) * max_rows * row_floats, count, ncclFloat, r, c->comm, stream);
 			}
 		} else {
 			const size_t count = static_cast<size_t>(bm::shard_rows(height, band_rows, c->rank, c->world)) * row_floats;
-			if (count) BM_NCCL(R->Send(packed_dev, count, ncclFloat, root, c->comm, stream));
+			if (count) first = R->Send(packed_dev, count, ncclFloat, root, c->comm, stream);
 		}
-		BM_NCCL(R->GroupEnd());
+		const ncclResult_t closed = R->GroupEnd();
+		if (first != ncclSuccess) return bm::nccl_fail(first, "ncclSend / ncclRecv of the packed row bands");
+		if (closed != ncclSuccess) return bm::nccl_fail(closed, "ncclGroupEnd");
 	}
 	if (c->rank == root) {
 		const long long n = static_cast<long long>(height) * width;
@@ -258,9 +262,11 @@ int bm_comm_selftest(bm_comm* c, void* hip_stream) {
 	BM_HIP(hipMemcpyAsync(c->word, &token, sizeof(int), hipMemcpyHostToDevice, stream));
 	BM_HIP(hipMemsetAsync(c->word + 1, 0, sizeof(int), stream));
 	BM_NCCL(R->GroupStart());
-	BM_NCCL(R->Send(c->word, 1, ncclInt, next, c->comm, stream));
-	BM_NCCL(R->Recv(c->word + 1, 1, ncclInt, prev, c->comm, stream));
-	BM_NCCL(R->GroupEnd());
+	ncclResult_t first = R->Send(c->word, 1, ncclInt, next, c->comm, stream);
+	if (first == ncclSuccess) first = R->Recv(c->word + 1, 1, ncclInt, prev, c->comm, stream);
+	const ncclResult_t closed = R->GroupEnd();
+	if (first != ncclSuccess) return bm::nccl_fail(first, "ncclSend / ncclRecv round the ring");
+	if (closed != ncclSuccess) return bm::nccl_fail(closed, "ncclGroupEnd");
 	// (b) a sum over all ranks
 	const int one = 1;
 	BM_HIP(hipMemcpyAsync(c->word + 2, &one, sizeof(int), hipMemcpyHostToDevice, stream));
