@@ -79,6 +79,8 @@ struct Params {
 	int minfill = 0; // pool mode: a wave that finds fewer lanes than this for every pass type sleeps while other waves hold slots
 	double beta = 0; // > 0: staged shutdown -- slot layer k is refilled only while the pixels left exceed k * beta * (lanes of the machine)
 	int nwaves = 0;
+	int twolaunch = 0; // 1: the hand-out order's first `split_tiles` tiles are one launch, the rest a second one whose workgroups start as the first's waves retire
+	int split_tiles = 0;
 	int split = 0; // 1: prepass launch (primary rays only, no shading), 2: the path launch that starts from the prepass's hit records
 	double cGen = 320, cRec = 40; // prepass: primary ray + set-up; writing the hit record
 	int rep = 1; // every pixel is handed out `rep` times (a steady-state / multi-sample frame: the drain is amortised)
@@ -189,6 +191,7 @@ struct Wave {
 	double ready = 0;
 	int my_counter = 0, counters_done = 0;
 	bool work_left = true, done = false;
+	bool second = false; // two-launch model: this wave slot now runs a workgroup of the second launch
 	double t_dry = -1, t_end = 0;
 };
 
@@ -197,6 +200,7 @@ struct Sim {
 	int W_img, H_img, tiles_x, tiles_y;
 	uint32_t total_chunks;
 	uint32_t counters[8] = {};
+	uint32_t counters2[8] = {};
 	Stats st;
 	uint64_t paths_done = 0, rays_done = 0;
 
@@ -225,11 +229,21 @@ struct Sim {
 		if (w.work_left && nI >= P.refill_min) {
 			if (P.pool && nI > 64) nI = 64; // one idle slot per column and refill
 			const int want = nI / 4;
-			const uint32_t base = counters[w.my_counter];
-			counters[w.my_counter] += (uint32_t)want;
 			const uint32_t total_groups = (total_chunks + 3u) >> 2;
 			const uint32_t my_groups = total_groups > (uint32_t)w.my_counter ? (total_groups - w.my_counter + 7u) / 8u : 0u;
-			const uint32_t my_tickets1 = my_groups * 4u * 4u, my_tickets = my_tickets1 * (uint32_t)P.rep;
+			const uint32_t my_tickets1 = my_groups * 4u * 4u;
+			uint32_t my_tickets = my_tickets1 * (uint32_t)P.rep;
+			uint32_t first_ticket = 0;
+			if (P.twolaunch) {
+				// tickets of this counter whose tile comes before split_tiles in the hand-out order: groups g = j * 8 + counter with (4 g) >> 4 < split_tiles
+				const uint32_t split_groups = (uint32_t)P.split_tiles * 4u; // 4 groups of 4 chunks per tile
+				const uint32_t ga = split_groups > (uint32_t)w.my_counter ? (split_groups - w.my_counter + 7u) / 8u : 0u;
+				const uint32_t ta = std::min(ga, my_groups) * 16u;
+				if (!w.second) my_tickets = ta; else first_ticket = ta;
+			}
+			uint32_t* ctr = w.second ? counters2 : counters;
+			const uint32_t base = first_ticket + ctr[w.my_counter];
+			ctr[w.my_counter] += (uint32_t)want;
 			const uint32_t counter_now = (uint32_t)w.my_counter;
 			if (base + want >= my_tickets) {
 				w.my_counter = (w.my_counter + 1) % 8;
@@ -283,7 +297,14 @@ struct Sim {
 		}
 		const int nA = nJ + nO;
 		if (live == 0 || (P.pool && busy_live > 0 && std::max(nA, std::max(nB, nC)) < P.minfill)) {
-			if (live == 0 && busy_live == 0 && !w.work_left) { w.done = true; return; }
+			if (live == 0 && busy_live == 0 && !w.work_left) {
+				if (P.twolaunch && !w.second) { // the first launch's workgroup retires; one of the second launch takes its place
+					w.second = true; w.work_left = true; w.counters_done = 0;
+					add(4, 50, 8.0); // dispatch of a new workgroup: a few microseconds
+					return;
+				}
+				w.done = true; return;
+			}
 			if (P.pool) { add(4, 12, 1.0); return; } // nothing (worth) running: s_sleep, look again later
 			add(4, sched_instr, 0); return;
 		}
@@ -390,7 +411,7 @@ int main(int argc, char** argv) {
 	std::map<std::string, double*> dk = {{"qB", &P.qB}, {"qC", &P.qC}, {"lat", &P.lat}, {"cpi", &P.cpi}, {"ovJ", &P.ovJ}, {"ovS", &P.ovS}, {"ovB", &P.ovB}, {"ovC", &P.ovC},
 										 {"sched", &P.schedMul}, {"cJ", &P.cJ}, {"cS", &P.cS}, {"cB", &P.cB}, {"cBstep", &P.cBstep}, {"cC", &P.cC}, {"cSched", &P.cSched}, {"cRefill", &P.cRefill}, {"wB", &P.wB}, {"wC", &P.wC}, {"beta", &P.beta}};
 	std::map<std::string, int*> ik = {{"K", &P.K}, {"W", &P.W}, {"refillmin", &P.refill_min}, {"tiles", &P.tiles}, {"policy", &P.policy}, {"jumpmin", &P.jump_min},
-									  {"jumppasses", &P.jump_passes}, {"steps", &P.steps_per_round}, {"rep", &P.rep}, {"pool", &P.pool}, {"minfill", &P.minfill}, {"split", &P.split}};
+									  {"jumppasses", &P.jump_passes}, {"steps", &P.steps_per_round}, {"rep", &P.rep}, {"pool", &P.pool}, {"minfill", &P.minfill}, {"split", &P.split}, {"twolaunch", &P.twolaunch}};
 	std::vector<std::string> sweeps;
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i];
@@ -452,7 +473,7 @@ int main(int argc, char** argv) {
 		}
 		g_tile_perm.resize(cost.size());
 		if (!strcmp(ord, "lpt")) { std::stable_sort(cost.begin(), cost.end(), [](auto& a, auto& b) { return a.first > b.first; }); for (size_t i = 0; i < cost.size(); ++i) g_tile_perm[i] = cost[i].second; }
-		else if (!strcmp(ord, "skylast")) { size_t k = 0; for (auto& c : cost) if (c.first > 1.0) g_tile_perm[k++] = c.second; for (auto& c : cost) if (c.first <= 1.0) g_tile_perm[k++] = c.second; }
+		else if (!strcmp(ord, "skylast")) { size_t k = 0; for (auto& c : cost) if (c.first > 1.0) g_tile_perm[k++] = c.second; P.split_tiles = (int)k; for (auto& c : cost) if (c.first <= 1.0) g_tile_perm[k++] = c.second; }
 		else if (!strcmp(ord, "bottomup")) { for (size_t i = 0; i < cost.size(); ++i) g_tile_perm[i] = uint32_t(cost.size() - 1 - i); }
 		else if (!strcmp(ord, "skyfirst_terrain_lpt")) { size_t k = 0; for (auto& c : cost) if (c.first <= 1.0) g_tile_perm[k++] = c.second; std::vector<std::pair<double, uint32_t>> rest; for (auto& c : cost) if (c.first > 1.0) rest.push_back(c); std::stable_sort(rest.begin(), rest.end(), [](auto& a, auto& b) { return a.first > b.first; }); for (auto& c : rest) g_tile_perm[k++] = c.second; }
 		else g_tile_perm.clear();
