@@ -215,26 +215,34 @@ __device__ __forceinline__ int move_axis(int last_step) {
 #define BM_JUMP_MIN 4 // smallest cube edge worth a jump (a jump costs about four single steps)
 #endif
 constexpr uint32_t kCubeNoJump = 0x100u; // RayState::cube flag: tmax is outside the range of jump.h, take single moves
-__device__ __forceinline__ int field_lookup(const DeviceScene& sc, RayState& r) {
+// The lookup in three pieces -- where the cell's byte lives, whether a jump may start from the current tmax, what the byte means
+// -- so that a kernel can issue the load in one pass and use the byte in a later one (trace_k.hip); field_lookup is their sum.
+__device__ __forceinline__ uint32_t field_index(const DeviceScene& sc, const RayState& r) {
 	const uint32_t fx = r.p & 0x7FFu, fy = (r.p >> 11) & 0x7FFu, fz = r.p >> 22;
 	// bordered cell coordinate = field - 15 (16-cell bias, one border cell): the three "- 15" are folded into sc.cube_field
-	const uint32_t idx = __umul24(fz, static_cast<uint32_t>(sc.cf_xy)) + (__umul24(fy, static_cast<uint32_t>(sc.cf_x)) + fx) + r.field_off;
-	const uint32_t v = sc.cube_field[idx];
+	return __umul24(fz, static_cast<uint32_t>(sc.cf_xy)) + (__umul24(fy, static_cast<uint32_t>(sc.cf_x)) + fx) + r.field_off;
+}
+__device__ __forceinline__ bool field_jump_possible(const RayState& r) { // jump_possible(): tmax in the range jump.h handles
 	const float m = fminf(fminf(r.tx, r.ty), r.tz);
+	return __float_as_uint(m) - kJumpMinBits < kJumpMaxBits - kJumpMinBits;
+}
+__device__ __forceinline__ int field_state(uint32_t v, bool possible, uint32_t& cube) {
 	// select-style, no short-circuit: a branchy version costs its full instruction count in a divergent wave anyway
-	const bool possible = __float_as_uint(m) - kJumpMinBits < kJumpMaxBits - kJumpMinBits; // jump_possible(): tmax in the range jump.h handles
-	r.cube = possible ? v : (v | kCubeNoJump); // remembered for the walk pass, which may be several scheduler rounds away
+	cube = possible ? v : (v | kCubeNoJump); // remembered for the walk pass, which may be several scheduler rounds away
 	const int jump = static_cast<int>(v >= static_cast<uint32_t>(BM_JUMP_MIN)) & static_cast<int>(possible);
 	int st = jump ? ST_JUMP : ST_OUTER;
 	st = v == 0u ? ST_CAND : st;
 	st = v == 255u ? ST_NEED : st; // left the grid (voxel.cuh:256): a miss
 	return st;
 }
+__device__ __forceinline__ int field_lookup(const DeviceScene& sc, RayState& r) {
+	const uint32_t v = sc.cube_field[field_index(sc, r)];
+	return field_state(v, field_jump_possible(r), r.cube);
+}
 
-// voxel.cuh:249-258: one Amanatides-Woo move to the next cell, then the new cell's byte.  Select-style (no per-axis branches);
-// `t += mask ? delta : 0` is the reference's `tmax += mask * tdelta` for finite deltas.
-template <bool DBG>
-__device__ __forceinline__ int field_step(const DeviceScene& sc, RayState& r, Tally& tally) {
+// voxel.cuh:249-258: one Amanatides-Woo move to the next cell.  Select-style (no per-axis branches); `t += mask ? delta : 0` is
+// the reference's `tmax += mask * tdelta` for finite deltas.
+__device__ __forceinline__ void step_advance(RayState& r) {
 	const float tx = r.tx, ty = r.ty, tz = r.tz;
 	const bool mx = tx < ty && tx < tz;
 	const bool my = ty <= tx && ty < tz; // mx implies !my
@@ -247,22 +255,28 @@ __device__ __forceinline__ int field_step(const DeviceScene& sc, RayState& r, Ta
 	r.tx = tx + (mx ? r.dx : 0.f);
 	r.ty = ty + (my ? r.dy : 0.f);
 	r.tz = tz + (mz ? r.dz : 0.f);
+}
+// ... then the new cell's byte
+template <bool DBG>
+__device__ __forceinline__ int field_step(const DeviceScene& sc, RayState& r, Tally& tally) {
+	step_advance(r);
 	const int st = field_lookup(sc, r);
 	if (DBG && st != ST_NEED) tally.index_loads++;
 	return st;
 }
 
-// Cross the empty cube ahead of the current cell (or as much of it as the current binade of tmax allows) in one go.
+// Cross the empty cube ahead of the current cell (or as much of it as the current binade of tmax allows) in one go; returns the
+// number of cells moved.
 // DIR: RayState::d holds the ray direction (the fused kernel); otherwise |direction| is recovered from tdelta with the
 // hardware reciprocal (the queue kernels keep the direction in the queue record, not in the pooled walk state) -- it only
 // feeds a quotient estimate that is corrected exactly (jump.h).
-template <bool DBG, bool DIR = true>
-__device__ __forceinline__ int field_jump(const DeviceScene& sc, RayState& r, Tally& tally) {
+template <bool DIR = true>
+__device__ __forceinline__ uint32_t jump_advance(RayState& r) {
 	uint32_t cx, cy, cz;
 	int axis;
 	float tx = r.tx, ty = r.ty, tz = r.tz;
 	const float dx = r.dx, dy = r.dy, dz = r.dz;
-	const int step_x = r.sx, step_y = r.stepy, step_z = r.stepz; // scalar copies, see field_step
+	const int step_x = r.sx, step_y = r.stepy, step_z = r.stepz; // scalar copies, see step_advance
 	const uint32_t n = r.cube & 0xFFu; // (a cell whose brick the ray just passed through has 0: one plain move, valid anywhere)
 	const float ix = DIR ? fabsf(r.d.x) : (dx > 0.f ? __builtin_amdgcn_rcpf(dx) : 0.f);
 	const float iy = DIR ? fabsf(r.d.y) : (dy > 0.f ? __builtin_amdgcn_rcpf(dy) : 0.f);
@@ -273,8 +287,13 @@ __device__ __forceinline__ int field_jump(const DeviceScene& sc, RayState& r, Ta
 	r.p += static_cast<uint32_t>(__mul24(static_cast<int>(cx), step_x) + __mul24(static_cast<int>(cy), step_y) + __mul24(static_cast<int>(cz), step_z));
 	r.last_step = axis == 0 ? step_x : (axis == 1 ? step_y : step_z); // (only read after a cube exit, where it is the exit axis)
 	r.last_axis = axis;
+	return cx + cy + cz;
+}
+template <bool DBG, bool DIR = true>
+__device__ __forceinline__ int field_jump(const DeviceScene& sc, RayState& r, Tally& tally) {
+	const uint32_t cells = jump_advance<DIR>(r);
 	const int st = field_lookup(sc, r);
-	if (DBG) tally.index_loads += cx + cy + cz - (st == ST_NEED ? 1u : 0u); // the cells the reference would have loaded: all but a final one outside the grid
+	if (DBG) tally.index_loads += cells - (st == ST_NEED ? 1u : 0u); // the cells the reference would have loaded: all but a final one outside the grid
 	return st;
 }
 

@@ -84,6 +84,10 @@ struct Params {
 	int split = 0; // 1: prepass launch (primary rays only, no shading), 2: the path launch that starts from the prepass's hit records
 	double cGen = 320, cRec = 40; // prepass: primary ray + set-up; writing the hit record
 	int rep = 1; // every pixel is handed out `rep` times (a steady-state / multi-sample frame: the drain is amortised)
+	int spill = 0; // > 0: drain compaction through a global queue -- a wave out of tickets with <= spill live lanes writes its paths' records to the queue and retires;
+	               // waves out of tickets with >= refill_min idle lanes take records from it; records nobody took are a follow-up launch's (modelled as a late pull)
+	int spill_keep = 0; // waves still running below which nobody spills any more (the tail is latency, not issue)
+	double cSpill = 120, cPull = 140;
 	double wB = 1.0, wC = 1.0; // policy 2: run the pass type with the largest (lanes * weight); the walk has weight 1
 };
 
@@ -203,6 +207,10 @@ struct Sim {
 	uint32_t counters2[8] = {};
 	Stats st;
 	uint64_t paths_done = 0, rays_done = 0;
+	std::vector<std::vector<Slot>> queue; // spill mode: published pages of path records (one page per spill)
+	bool final_launch = false; // the follow-up launch: takes pages, spills nothing
+	int waves_running = 0;
+	uint64_t spilled = 0, pulled = 0, late = 0, spill_events = 0;
 
 	// one scheduler round of a wave: applies the functional effects now, returns the issue / latency segments it costs
 	void round(Wave& w, double now) {
@@ -282,6 +290,26 @@ struct Sim {
 			add(4, sched_instr, 1.5); // the atomic's round trip
 			sched_instr = 0;
 			if (P.pool) return; // pool mode: a refill is a round of its own (the claimed slots are published at the next one)
+		}
+		if (P.spill && !w.work_left) {
+			int nlive = 0, nidle = 0;
+			for (auto& sl : slots) { nlive += sl.st != S_IDLE; nidle += sl.st == S_IDLE; }
+			if (!final_launch && nlive > 0 && nlive <= P.spill && waves_running > P.spill_keep) {
+				queue.emplace_back();
+				for (auto& sl : slots) if (sl.st != S_IDLE) { queue.back().push_back(sl); sl.st = S_IDLE; sl.ray = nullptr; }
+				spilled += nlive; spill_events++;
+				add(4, P.cSpill, 1.0);
+				waves_running--;
+				w.done = true; return;
+			}
+			if (nidle >= P.spill && !queue.empty()) { // any page fits
+				std::vector<Slot> page = std::move(queue.front()); queue.erase(queue.begin());
+				for (auto& sl : slots) if (sl.st == S_IDLE && !page.empty()) { sl = page.back(); page.pop_back(); }
+				pulled++; if (final_launch) late++;
+				add(4, P.cPull, 2.5); // claim (atomic round trip), then the records
+				return;
+			}
+			if (nlive == 0) { waves_running--; w.done = true; return; }
 		}
 		// ---- counts: columns in which ANY available slot wants the pass
 		int nJ = 0, nO = 0, nB = 0, nC = 0, live = 0, busy_live = 0;
@@ -409,9 +437,9 @@ struct Sim {
 int main(int argc, char** argv) {
 	Params P;
 	std::map<std::string, double*> dk = {{"qB", &P.qB}, {"qC", &P.qC}, {"lat", &P.lat}, {"cpi", &P.cpi}, {"ovJ", &P.ovJ}, {"ovS", &P.ovS}, {"ovB", &P.ovB}, {"ovC", &P.ovC},
-										 {"sched", &P.schedMul}, {"cJ", &P.cJ}, {"cS", &P.cS}, {"cB", &P.cB}, {"cBstep", &P.cBstep}, {"cC", &P.cC}, {"cSched", &P.cSched}, {"cRefill", &P.cRefill}, {"wB", &P.wB}, {"wC", &P.wC}, {"beta", &P.beta}};
+										 {"sched", &P.schedMul}, {"cJ", &P.cJ}, {"cS", &P.cS}, {"cB", &P.cB}, {"cBstep", &P.cBstep}, {"cC", &P.cC}, {"cSched", &P.cSched}, {"cRefill", &P.cRefill}, {"wB", &P.wB}, {"wC", &P.wC}, {"beta", &P.beta}, {"cSpill", &P.cSpill}, {"cPull", &P.cPull}};
 	std::map<std::string, int*> ik = {{"K", &P.K}, {"W", &P.W}, {"refillmin", &P.refill_min}, {"tiles", &P.tiles}, {"policy", &P.policy}, {"jumpmin", &P.jump_min},
-									  {"jumppasses", &P.jump_passes}, {"steps", &P.steps_per_round}, {"rep", &P.rep}, {"pool", &P.pool}, {"minfill", &P.minfill}, {"split", &P.split}, {"twolaunch", &P.twolaunch}};
+									  {"jumppasses", &P.jump_passes}, {"steps", &P.steps_per_round}, {"rep", &P.rep}, {"pool", &P.pool}, {"minfill", &P.minfill}, {"split", &P.split}, {"twolaunch", &P.twolaunch}, {"spill", &P.spill}, {"spillkeep", &P.spill_keep}};
 	std::vector<std::string> sweeps;
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i];
@@ -498,31 +526,43 @@ int main(int argc, char** argv) {
 					simd[cu * 4 + (j % 4)].push_back(std::move(w));
 				}
 			}
+		sim.waves_running = nsimd * P.W;
 		struct Ev { double t; int s; bool operator<(const Ev& o) const { return t > o.t; } };
-		std::priority_queue<Ev> pq;
 		std::vector<double> tnow(nsimd, 0.0);
-		for (int s = 0; s < nsimd; ++s) pq.push(Ev{0.0, s});
 		double t_last = 0, busy = 0, drain_sum = 0, life_sum = 0;
-		while (!pq.empty()) {
-			const Ev e = pq.top(); pq.pop();
-			auto& waves = simd[e.s];
-			// pick the ready wave with the earliest ready time
-			Wave* best = nullptr;
-			for (auto& w : waves) if (!w.done && (!best || w.ready < best->ready)) best = &w;
-			if (!best) continue;
-			double t = std::max(tnow[e.s], best->ready);
-			if (best->pend_i >= best->pending.size()) {
-				best->pending.clear(); best->pend_i = 0;
-				sim.round(*best, t);
-				if (best->done) { best->t_end = t; t_last = std::max(t_last, t); life_sum += t; if (best->t_dry >= 0) drain_sum += t - best->t_dry; pq.push(Ev{t, e.s}); continue; }
+		auto run_launch = [&](double t0) {
+			std::priority_queue<Ev> pq;
+			for (int s = 0; s < nsimd; ++s) { tnow[s] = t0; pq.push(Ev{t0, s}); }
+			while (!pq.empty()) {
+				const Ev e = pq.top(); pq.pop();
+				auto& waves = simd[e.s];
+				// pick the ready wave with the earliest ready time
+				Wave* best = nullptr;
+				for (auto& w : waves) if (!w.done && (!best || w.ready < best->ready)) best = &w;
+				if (!best) continue;
+				double t = std::max(tnow[e.s], best->ready);
+				if (best->pend_i >= best->pending.size()) {
+					best->pending.clear(); best->pend_i = 0;
+					sim.round(*best, t);
+					if (best->done) { best->t_end = t; t_last = std::max(t_last, t); life_sum += t - t0; if (best->t_dry >= 0) drain_sum += t - best->t_dry; pq.push(Ev{t, e.s}); continue; }
+				}
+				if (best->pend_i < best->pending.size()) {
+					const Seg sg = best->pending[best->pend_i++];
+					t += sg.issue; busy += sg.issue;
+					best->ready = t + sg.lat;
+				}
+				tnow[e.s] = t;
+				pq.push(Ev{t, e.s});
 			}
-			if (best->pend_i < best->pending.size()) {
-				const Seg sg = best->pending[best->pend_i++];
-				t += sg.issue; busy += sg.issue;
-				best->ready = t + sg.lat;
-			}
-			tnow[e.s] = t;
-			pq.push(Ev{t, e.s});
+		};
+		run_launch(0.0);
+		const double t_first = t_last;
+		size_t left_pages = sim.queue.size();
+		if (P.spill && !sim.queue.empty()) { // the follow-up launch: the same grid, no tickets, takes what nobody took
+			sim.final_launch = true;
+			for (auto& ws : simd) for (auto& w : ws) { w.done = false; w.work_left = false; w.t_dry = t_last + 12000; w.ready = t_last + 12000; w.pending.clear(); w.pend_i = 0; }
+			sim.waves_running = nsimd * P.W;
+			run_launch(t_last + 12000); // ~5 us between the launches
 		}
 		const Stats& S = sim.st;
 		const double scale = P.tiles > 1 ? P.tiles : 1; // report per full frame
@@ -537,6 +577,7 @@ int main(int argc, char** argv) {
 		}
 		printf("   brick loop %.1f cells;  sched+refill %.1fM instr;  total %.3fG wave instr, lanes/instr %.1f\n", S.brick_loop / std::max(1.0, S.brick_passes), S.instr[4] * scale / 1e6, total_instr * scale / 1e9,
 			   lane_instr / (total_instr - S.instr[4]));
+		if (P.spill) printf("   spill <= %d lanes (keep %d waves): %llu records in %llu spills, %llu taken in-kernel, %zu pages left to the follow-up launch (first launch ends at %.3f ms)\n", P.spill, P.spill_keep, (unsigned long long)sim.spilled, (unsigned long long)sim.spill_events, (unsigned long long)(sim.pulled - sim.late), left_pages, t_first / 2.4e6);
 		if (g_lookups) printf("   coarse level (min over 4x4x4 blocks): of %.1fM field lookups, block-min >= 2 / 4 / 8 / 16: %.1f %% / %.1f %% / %.1f %% / %.1f %%\n", g_lookups / 1e6,
 							  100.0 * g_coarse_hits[0] / g_lookups, 100.0 * g_coarse_hits[1] / g_lookups, 100.0 * g_coarse_hits[2] / g_lookups, 100.0 * g_coarse_hits[3] / g_lookups);
 		printf("   frame %.3f ms (slowest SIMD at 2.4 GHz), SIMD issue busy %.1f %%, drain %.1f %% of wave lifetime\n", t_last / 2.4e6, 100.0 * busy / (t_last * nsimd), 100.0 * drain_sum / life_sum);
