@@ -485,6 +485,9 @@ int trace_k_blocks_per_cu(bool instrumented) {
 	int n = 0;
 	const hipError_t e = instrumented ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths_k<true>, 256, 0)
 									  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths_k<false>, 256, 0);
+#ifdef BM_K_MAX_BLOCKS // occupancy experiments: fewer resident workgroups per CU than the LDS allows
+	if (n > BM_K_MAX_BLOCKS) n = BM_K_MAX_BLOCKS;
+#endif
 	return e == hipSuccess && n > 0 ? n : 1;
 }
 size_t trace_k_scratch_bytes(bool instrumented, int resident_blocks) {
