@@ -106,19 +106,36 @@ def _make_comm(device_index, group):
     """The C-ABI communicator for a process group, checked before it is relied on: every rank runs bm_comm_selftest (a grouped
     send / receive round the ring of ranks + an all-reduce, data verified) and the ranks agree on the outcome -- if the
     communicator cannot be made or the check fails on ANY rank, all of them fall back to torch.distributed's exchange."""
+    import sys
     import torch
     import torch.distributed as dist
+    dev = torch.device("cuda", device_index) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+    def agreed(ok):
+        t = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return int(t.item()) == 1
+
+    # 1. can every rank bind the library at all?  (A rank that failed later, inside from_process_group, would leave the others
+    #    waiting in the id's broadcast or in ncclCommInitRank: settle it while nobody depends on anybody yet.)
+    why = None
+    try:
+        Comm.unique_id()
+    except Exception as e:  # noqa: BLE001
+        why = e
+    if not agreed(0 if why else 1):
+        if why is not None:
+            print(f"brickmap_amd.dist: C-ABI RCCL exchange unavailable ({why}); using torch.distributed", file=sys.stderr)
+        return None
+    # 2. the communicator, then its self-test
     comm, ok = None, 1
     try:
         comm = Comm.from_process_group(device_index, group)
         comm.selftest()
     except Exception as e:  # noqa: BLE001 -- anything at all: the render must not depend on it
         ok = 0
-        import sys
         print(f"brickmap_amd.dist: C-ABI RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
-    t = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", device_index) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
-    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-    if int(t.item()) != 1:
+    if not agreed(ok):
         if comm is not None:
             comm.close()
         return None
