@@ -44,31 +44,31 @@ struct Rccl {
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 
-Rccl* rccl() {
-	static Rccl api;
-	static bool tried = false;
-	if (!tried) {
-		tried = true;
-		// BM_RCCL_LIBRARY names a specific build of the library (a site's own RCCL; the tests' host-staged stand-in that lets
-		// several ranks share one GPU, tests/fake_rccl.cpp)
-		const char* names[] = {std::getenv("BM_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-		for (const char* n : names) {
-			if (!n || !*n) continue;
-			api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-			if (api.lib) break;
-		}
-		if (api.lib) {
+Rccl bind_rccl() {
+	Rccl api;
+	// BM_RCCL_LIBRARY names a specific build of the library (a site's own RCCL; the tests' host-staged stand-in that lets
+	// several ranks share one GPU, tests/fake_rccl.cpp)
+	const char* names[] = {std::getenv("BM_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+	for (const char* n : names) {
+		if (!n || !*n) continue;
+		api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+		if (api.lib) break;
+	}
+	if (api.lib) {
 #define BM_SYM(name) api.name = reinterpret_cast<decltype(api.name)>(dlsym(api.lib, "nccl" #name))
-			BM_SYM(GetUniqueId); BM_SYM(CommInitRank); BM_SYM(CommDestroy); BM_SYM(GroupStart); BM_SYM(GroupEnd);
-			BM_SYM(Send); BM_SYM(Recv); BM_SYM(Reduce); BM_SYM(AllReduce); BM_SYM(GetErrorString);
+		BM_SYM(GetUniqueId); BM_SYM(CommInitRank); BM_SYM(CommDestroy); BM_SYM(GroupStart); BM_SYM(GroupEnd);
+		BM_SYM(Send); BM_SYM(Recv); BM_SYM(Reduce); BM_SYM(AllReduce); BM_SYM(GetErrorString);
 #undef BM_SYM
-			if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Send || !api.Recv || !api.Reduce ||
-				!api.AllReduce || !api.GetErrorString) {
-				dlclose(api.lib);
-				api.lib = nullptr;
-			}
+		if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Send || !api.Recv || !api.Reduce ||
+			!api.AllReduce || !api.GetErrorString) {
+			dlclose(api.lib);
+			api.lib = nullptr;
 		}
 	}
+	return api;
+}
+Rccl* rccl() {
+	static Rccl api = bind_rccl(); // (a function-local static: bound once, also when several host threads make communicators at the same time)
 	return api.lib ? &api : nullptr;
 }
 
