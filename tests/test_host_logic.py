@@ -2,6 +2,8 @@
 row sharding, the CPU world builder against the oracle, and the layering rules."""
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -33,6 +35,32 @@ def test_error_reporting_without_gpu(bm):
     import ctypes as C
     out = np.zeros((128, 128), np.float32)
     assert L.bm_host_column_heights(100, 128, 0, 0, out.ctypes.data) == 10001  # not a multiple of 128
+
+
+def test_comm_argument_errors_without_gpu(bm, tmp_path):
+    """The exchange's entry points refuse bad arguments before they touch RCCL or a device, and a missing RCCL library is an
+    error code with a message, not a crash (checked in a child process: the binding is made once per process)."""
+    import ctypes as C
+    from brickmap_amd import _lib
+    L = _lib.load()
+    h = C.c_void_p()
+    idbuf = (C.c_ubyte * 128)()
+    assert L.bm_comm_create(0, 2, 2, idbuf, C.byref(h)) == 10001 and b"bad argument" in L.bm_last_error_string()   # rank outside the world
+    assert L.bm_comm_create(0, 0, 0, idbuf, C.byref(h)) == 10001
+    assert L.bm_comm_create(0, 0, 1, None, C.byref(h)) == 10001
+    assert L.bm_comm_unique_id(None) == 10001
+    assert L.bm_gather_frame(None, None, None, 16, 16, 16, 0, None) == 10001 and b"null communicator" in L.bm_last_error_string()
+    assert L.bm_reduce_frame(None, None, None, 0, 0, None) == 10001
+    assert L.bm_comm_barrier(None, None) == 10001 and L.bm_comm_selftest(None, None) == 10001
+    assert L.bm_comm_info(None, None, None) == 10001
+    L.bm_comm_destroy(None)  # a no-op
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from brickmap_amd import _lib; L = _lib.load(); b = (C.c_ubyte * 128)(); "
+            "r = L.bm_comm_unique_id(b); print(r, L.bm_last_error_string().decode())" % ROOT)
+    env = dict(os.environ, BM_RCCL_LIBRARY=str(tmp_path / "no_such_rccl.so"), LD_LIBRARY_PATH="")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    # either the named library is missing and a system RCCL was found instead (an id is made: 0), or nothing binds: BM_ESTATE with a message
+    assert out.stdout.startswith("0 ") or ("10002" in out.stdout and "not found" in out.stdout), out.stdout
 
 
 def test_local_rows_matches_shard_rows(bm):
