@@ -71,6 +71,7 @@ struct FrameConstants {
 	int band_rows, shard_rank, shard_count, local_rows;
 	// launch geometry
 	int tiles_x, tiles_y; // 16x16-pixel tiles covering this shard's rows
+	int refill_min;       // a wave takes new work items once this many of its lanes are idle (frame_constants(): by the length of an item)
 };
 
 struct DeviceCounters { // v: same order as bm_counters; sched: same order as bm_sched_stats

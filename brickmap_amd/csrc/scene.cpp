@@ -114,6 +114,13 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp,
 	fc->local_rows = bm_local_rows(fp);
 	fc->tiles_x = (fp->width + 15) / 16;
 	fc->tiles_y = (fc->local_rows + 15) / 16;
+	// When does a wave stop to refill?  Every refill costs the whole wave an atomic's round trip and ~110 instructions, every idle
+	// lane costs its share of all passes until then.  An item is all samples of a pixel (or ONE with BM_FLAG_SAMPLE_ITEMS): the
+	// longer it is, the rarer the refills, the earlier they pay (measured per workload, profiles/r04_refill_sweep.txt).
+	const int samples_per_item = (fp->flags & BM_FLAG_SAMPLE_ITEMS) ? 1 : fp->spp;
+	fc->refill_min = samples_per_item >= 4 ? 4 : (samples_per_item >= 2 ? 8 : 16);
+	static const int refill_override = [] { const char* e = std::getenv("BM_REFILL_MIN"); return e ? std::atoi(e) : 0; }(); // tuning runs
+	if (refill_override >= 1 && refill_override <= 64) fc->refill_min = refill_override;
 	return 0;
 }
 

@@ -18,8 +18,8 @@ namespace bm {
 // Persistent-wave path tracer.
 //
 // Work distribution: the shard's pixels are cut into 4x4-pixel chunks (ordered so that four consecutive
-// chunks form an 8x8 block and sixteen a 16x16 tile).  Waves are persistent: whenever 16 or more of a
-// wave's lanes have no pixel, the wave takes that many pixels, in 4x1 rows of consecutive chunks, from a global
+// chunks form an 8x8 block and sixteen a 16x16 tile).  Waves are persistent: whenever FrameConstants::refill_min or more of a
+// wave's lanes have no pixel (16 for one-sample items, fewer for long ones), the wave takes that many pixels, pixel by pixel through consecutive 4x4 chunks, from a global
 // counter (one atomic per refill) and hands one pixel to each idle lane.  A lane traces ALL samples of its pixel, in order, before
 // it takes another one, so each pixel's accumulation order is fixed (sample by sample, event by event).
 //
@@ -41,7 +41,10 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #define BM_WAVES_PER_SIMD 5
 #endif
 #ifndef BM_ITEM_LANES
-#define BM_ITEM_LANES 4 // pixels handed out per ticket: a 4x1 row of a 4x4 chunk (16 = whole chunks: 2.5 % slower, a refill then leaves up to 15 idle lanes empty)
+// pixels handed out per ticket: 1 = a refill fills EVERY idle lane (consecutive tickets still walk through a 4x4 chunk row by row).
+// 4 (a 4x1 row per ticket: up to 3 idle lanes stay empty) is 1 % slower on every workload, 16 (whole chunks) 2.5 %
+// (profiles/r04_refill_sweep.txt)
+#define BM_ITEM_LANES 1
 #endif
 // Wave priorities (s_setprio) per pass: a wave in a walk or candidate pass -- short, and ending in a dependent load -- issues
 // before a wave in the long arithmetic of a shade pass, which fills the gaps: 1.169 -> 1.118 ms on config 2 (any of
@@ -75,9 +78,6 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #endif
 #ifndef BM_STEPS_PER_ROUND
 #define BM_STEPS_PER_ROUND 4
-#endif
-#ifndef BM_REFILL_MIN
-#define BM_REFILL_MIN 16
 #endif
 // -DBM_PHASE_TIMING: profiling build in which the plain kernel also reports the scheduler statistics
 #ifdef BM_PHASE_TIMING
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		// ---- refill: hand pixels to idle lanes, BM_ITEM_LANES at a time (consecutive tickets walk through a 4x4 chunk)
 		const unsigned long long idle = __ballot(state == ST_IDLE);
 		const int nI = __popcll(idle);
-		if (work_left && nI >= BM_REFILL_MIN) {
+		if (work_left && nI >= fc.refill_min) {
 			// One global word serves only ~90 returning atomics per microsecond chip-wide, and a refill stalls the whole
 			// wave until its atomic returns; with thousands of waves on one counter that queue is tens of microseconds
 			// long.  The chunk sequence is therefore dealt to kCounters interleaved counters (8x8-pixel groups of four
