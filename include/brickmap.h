@@ -43,7 +43,9 @@ extern "C" {
                                    holds an order-independent digest per pixel: words 4-7 are the SUMS (mod 2^32) over the
                                    samples of the per-sample path hashes / ray counts / cell counts (zero the buffer first),
                                    words 0-3 the first-hit record of the launch's first sample.
-                                   For shards with few pixels and many samples, e.g. 1/N row bands of a multi-GPU frame */
+                                   For shards with few pixels and many samples, e.g. 1/N row bands of a multi-GPU frame; also the
+                                   faster mode of any frame with several samples per pixel (1080p at 4 spp: 3.7 ms against 4.4,
+                                   4K at 4 spp: 23.0 against 24.0 -- shorter items, shorter tail) when a fixed summation order is not needed */
 
 #define BM_FLAG_KSLOT 8u        /* run this frame with the K-slot schedule (csrc/trace_k.hip: K paths per lane, path state in LDS):
                                    same paths, same per-pixel event order, hit records bit-identical to the default schedule's
