@@ -88,6 +88,7 @@ struct Params {
 	               // waves out of tickets with >= refill_min idle lanes take records from it; records nobody took are a follow-up launch's (modelled as a late pull)
 	int spill_keep = 0; // waves still running below which nobody spills any more (the tail is latency, not issue)
 	double cSpill = 120, cPull = 140;
+	double refillLat = 1.5; // load latencies a refill stalls its wave for (the atomic's round trip); 0 models tickets fetched ahead of time
 	double wB = 1.0, wC = 1.0; // policy 2: run the pass type with the largest (lanes * weight); the walk has weight 1
 };
 
@@ -287,7 +288,7 @@ struct Sim {
 				rank++;
 			}
 			sched_instr += P.cRefill;
-			add(4, sched_instr, 1.5); // the atomic's round trip
+			add(4, sched_instr, P.refillLat); // the atomic's round trip
 			sched_instr = 0;
 			if (P.pool) return; // pool mode: a refill is a round of its own (the claimed slots are published at the next one)
 		}
@@ -437,7 +438,7 @@ struct Sim {
 int main(int argc, char** argv) {
 	Params P;
 	std::map<std::string, double*> dk = {{"qB", &P.qB}, {"qC", &P.qC}, {"lat", &P.lat}, {"cpi", &P.cpi}, {"ovJ", &P.ovJ}, {"ovS", &P.ovS}, {"ovB", &P.ovB}, {"ovC", &P.ovC},
-										 {"sched", &P.schedMul}, {"cJ", &P.cJ}, {"cS", &P.cS}, {"cB", &P.cB}, {"cBstep", &P.cBstep}, {"cC", &P.cC}, {"cSched", &P.cSched}, {"cRefill", &P.cRefill}, {"wB", &P.wB}, {"wC", &P.wC}, {"beta", &P.beta}, {"cSpill", &P.cSpill}, {"cPull", &P.cPull}};
+										 {"sched", &P.schedMul}, {"cJ", &P.cJ}, {"cS", &P.cS}, {"cB", &P.cB}, {"cBstep", &P.cBstep}, {"cC", &P.cC}, {"cSched", &P.cSched}, {"cRefill", &P.cRefill}, {"wB", &P.wB}, {"wC", &P.wC}, {"beta", &P.beta}, {"cSpill", &P.cSpill}, {"cPull", &P.cPull}, {"refillLat", &P.refillLat}};
 	std::map<std::string, int*> ik = {{"K", &P.K}, {"W", &P.W}, {"refillmin", &P.refill_min}, {"tiles", &P.tiles}, {"policy", &P.policy}, {"jumpmin", &P.jump_min},
 									  {"jumppasses", &P.jump_passes}, {"steps", &P.steps_per_round}, {"rep", &P.rep}, {"pool", &P.pool}, {"minfill", &P.minfill}, {"split", &P.split}, {"twolaunch", &P.twolaunch}, {"spill", &P.spill}, {"spillkeep", &P.spill_keep}};
 	std::vector<std::string> sweeps;
