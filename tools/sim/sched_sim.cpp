@@ -440,7 +440,7 @@ int main(int argc, char** argv) {
 	std::map<std::string, double*> dk = {{"qB", &P.qB}, {"qC", &P.qC}, {"lat", &P.lat}, {"cpi", &P.cpi}, {"ovJ", &P.ovJ}, {"ovS", &P.ovS}, {"ovB", &P.ovB}, {"ovC", &P.ovC},
 										 {"sched", &P.schedMul}, {"cJ", &P.cJ}, {"cS", &P.cS}, {"cB", &P.cB}, {"cBstep", &P.cBstep}, {"cC", &P.cC}, {"cSched", &P.cSched}, {"cRefill", &P.cRefill}, {"wB", &P.wB}, {"wC", &P.wC}, {"beta", &P.beta}, {"cSpill", &P.cSpill}, {"cPull", &P.cPull}, {"refillLat", &P.refillLat}};
 	std::map<std::string, int*> ik = {{"K", &P.K}, {"W", &P.W}, {"refillmin", &P.refill_min}, {"tiles", &P.tiles}, {"policy", &P.policy}, {"jumpmin", &P.jump_min},
-									  {"jumppasses", &P.jump_passes}, {"steps", &P.steps_per_round}, {"rep", &P.rep}, {"pool", &P.pool}, {"minfill", &P.minfill}, {"split", &P.split}, {"twolaunch", &P.twolaunch}, {"spill", &P.spill}, {"spillkeep", &P.spill_keep}};
+									  {"jumppasses", &P.jump_passes}, {"steps", &P.steps_per_round}, {"rep", &P.rep}, {"pool", &P.pool}, {"minfill", &P.minfill}, {"split", &P.split}, {"twolaunch", &P.twolaunch}, {"spill", &P.spill}, {"spillkeep", &P.spill_keep}, {"splittiles", &P.split_tiles}};
 	std::vector<std::string> sweeps;
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i];
