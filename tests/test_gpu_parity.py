@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -1089,3 +1089,40 @@ def test_kslot_counters(bm, torch_cuda, scene256, world256, orc):
     st = scene256.sched_stats()
     assert st["waves"] > 0 and st["jump_runs"] > 0 and st["candidate_runs"] > 0 and st["shade_runs"] > 0
     scene256.counters_reset()
+
+
+@pytest.mark.gpu
+def test_refill_threshold_changes_nothing_but_time(bm, torch_cuda, tmp_path):
+    """FrameConstants::refill_min (scene.cpp frame_constants: 16 / 8 / 4 idle lanes by the samples per work item, BM_REFILL_MIN
+    overrides it per process) decides WHEN a wave takes new pixels, never what a path computes: the same frames -- 1, 2 and 5 samples
+    per pixel, pixel items and (chunk, sample) items' hit digests -- bit for bit under the rule and under forced thresholds."""
+    code = r'''
+import sys, hashlib
+sys.path.insert(0, %r)
+import numpy as np, torch, brickmap_amd as bm
+scene = bm.Scene(256, 256, device=0).generate().preload_all()
+cam = bm.Camera(position=(128.0, 40.0, 200.0), horizontal_angle=0.9, vertical_angle=-0.6).update()
+h = hashlib.sha256()
+for spp, flags in ((1, 0), (2, 0), (5, 0), (3, bm.BM_FLAG_SAMPLE_ITEMS)):
+    p = bm.FrameParams(97, 61, spp=spp, max_bounces=3, flags=flags)
+    acc = torch.zeros((61, 97, 4), dtype=torch.float32, device="cuda:0")
+    dbg = torch.zeros((61, 97, 8), dtype=torch.int32, device="cuda:0")
+    scene.render(cam, p, acc, debug=dbg)
+    torch.cuda.synchronize()
+    h.update(dbg.cpu().numpy().tobytes())
+    if not flags:
+        h.update(acc.cpu().numpy().tobytes())   # (float atomics: the sum's order is free with sample items)
+print("DIGEST", h.hexdigest())
+''' % ROOT
+    import subprocess
+    import sys
+    digests = {}
+    for v in ("", "1", "4", "16", "33", "64"):
+        env = dict(os.environ)
+        env.pop("BM_REFILL_MIN", None)
+        if v:
+            env["BM_REFILL_MIN"] = v
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests[v or "rule"] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
+    assert len(set(digests.values())) == 1, digests
