@@ -14,7 +14,7 @@ kernel's own duration then includes the time it shares the GPU); the N = 1 line 
 (`pipelined`), never as `value`.
 
 N > 1 STRONG-scales one fixed job with the north-star decomposition: the same 1080p / 4-segment frame at
-MULTI_GPU_SPP = 8 samples per pixel, cut into interleaved 16-row bands (band b belongs to rank b % N); every rank traces
+MULTI_GPU_SPP = 8 samples per pixel, cut into interleaved 8-row bands (band b belongs to rank b % N); every rank traces
 all 8 samples of its rows into a packed float4 buffer (work items = (4x4 chunk, sample) pairs, BM_FLAG_SAMPLE_ITEMS, so
 the persistent waves stay fed on 1/N of the pixels), and the packed bands are gathered to rank 0 over RCCL/xGMI
 (brickmap_amd/dist.py FrameGatherer: grouped send/recv, 33 MB / N per peer per step).  The gather of step i overlaps the
@@ -373,46 +373,57 @@ def main():
             torch.cuda.synchronize()
             same_job = {"error": repr(e)}
 
-    # ---- what the N > 1 lines should come out at, measured on THIS GPU (N = 1 / config 2 line only, untimed extra): rank 0's
-    # 1/N shard of the same 8-spp job (interleaved 16-row bands, (chunk, sample) items), N = 2 / 4 / 8, consecutive steps on one
+    # ---- what the N > 1 lines should come out at, measured on THIS GPU (N = 1 / config 2 line only, untimed extra): every rank's
+    # 1/N shard of the same 8-spp job (interleaved row bands, (chunk, sample) items; the slowest rank counts), N = 2 / 4 / 8, consecutive steps on one
     # stream.  predicted_speedup = unsharded job time / shard time: the kernels alone, before the gather (4.1 MB per peer per
     # step at N = 8, issued behind the frame and overlapped with the next one).  The first real SCALE run is checked against it.
     shard_pred = None
     if not multi and args.workload == "config2" and not streaming and not args.no_extras and same_job is not None and "ms_per_step" in same_job:
         try:
             shard_pred = {"job": same_job["workload"], "unsharded_ms_per_step": same_job["ms_per_step"], "shard_kernel_ms": {}, "shard_ms_per_step": {},
-                          "predicted_speedup": {}, "note": "rank 0's shard of the job on this GPU, no gather.  --gpus N runs every rank's steps on two alternating streams by default: "
+                          "predicted_speedup": {}, "note": "every rank's shard of the job timed on this GPU, one after the other, no gather; shard_* = the SLOWEST rank.  --gpus N runs every rank's steps on two alternating streams by default: "
                           "value(N) / (the unsharded job's rate on one GPU) should come out near predicted_speedup_two_streams[N] "
                           "(predicted_speedup[N] with --pipeline 1)"}
             two = pick_streams(2)
             shard_pred["shard_ms_per_step_two_streams"], shard_pred["predicted_speedup_two_streams"] = {}, {}
+            shard_pred["band_rows"] = band
+            shard_pred["per_rank_ms_per_step"], shard_pred["per_rank_ms_per_step_two_streams"] = {}, {}
             for n_ranks in (2, 4, 8):
-                st = bm.State(W, H, device=local_rank, band_rows=band, shard_rank=0, shard_count=n_ranks)
-                bufs = [st.blit_buffer, torch.zeros_like(st.blit_buffer)]
-                ps = lambda i: bm.FrameParams(W, H, spp=job_spp, sample_base=7000 + i * job_spp, max_bounces=max_bounces, flags=bm.BM_FLAG_SAMPLE_ITEMS,
-                                              band_rows=band, shard_rank=0, shard_count=n_ranks)
-                ns = 6
-                for i in range(2):
-                    scene.render(cam, ps(i), st.blit_buffer)
-                torch.cuda.synchronize()
-                ts = time.perf_counter()
-                for i in range(ns):
-                    scene.render(cam, ps(2 + i), st.blit_buffer)
-                torch.cuda.synchronize()
-                ss = (time.perf_counter() - ts) / ns * 1e3
-                shard_pred["shard_ms_per_step"][str(n_ranks)] = round(ss, 4)
-                shard_pred["shard_kernel_ms"][str(n_ranks)] = round(float(np.mean(scene.render_times(ns))), 4)
-                shard_pred["predicted_speedup"][str(n_ranks)] = round(same_job["ms_per_step"] / ss, 3)
-                for rep in range(2):  # (the first repetition warms the second stream up)
+                # EVERY rank's shard, one after the other: the job is as fast as its slowest rank (the bands differ in rows -- 1080 rows
+                # are 135 bands of 8 -- and in what they show)
+                ones, twos, kern = [], [], []
+                for r in range(n_ranks):
+                    st = bm.State(W, H, device=local_rank, band_rows=band, shard_rank=r, shard_count=n_ranks)
+                    bufs = [st.blit_buffer, torch.zeros_like(st.blit_buffer)]
+                    ps = lambda i: bm.FrameParams(W, H, spp=job_spp, sample_base=7000 + i * job_spp, max_bounces=max_bounces, flags=bm.BM_FLAG_SAMPLE_ITEMS,
+                                                  band_rows=band, shard_rank=r, shard_count=n_ranks)
+                    ns = 6
+                    for i in range(2):
+                        scene.render(cam, ps(i), st.blit_buffer)
                     torch.cuda.synchronize()
                     ts = time.perf_counter()
-                    for i in range(2 * ns):
-                        scene.render(cam, ps(10 + i), bufs[i % 2], stream=two[i % 2].cuda_stream)
+                    for i in range(ns):
+                        scene.render(cam, ps(2 + i), st.blit_buffer)
                     torch.cuda.synchronize()
-                    s2 = (time.perf_counter() - ts) / (2 * ns) * 1e3
-                shard_pred["shard_ms_per_step_two_streams"][str(n_ranks)] = round(s2, 4)
-                shard_pred["predicted_speedup_two_streams"][str(n_ranks)] = round(same_job["ms_per_step"] / s2, 3)
-                del st, bufs
+                    ones.append((time.perf_counter() - ts) / ns * 1e3)
+                    kern.append(float(np.mean(scene.render_times(ns))))
+                    for rep in range(2):  # (the first repetition warms the second stream up)
+                        torch.cuda.synchronize()
+                        ts = time.perf_counter()
+                        for i in range(2 * ns):
+                            scene.render(cam, ps(10 + i), bufs[i % 2], stream=two[i % 2].cuda_stream)
+                        torch.cuda.synchronize()
+                        s2 = (time.perf_counter() - ts) / (2 * ns) * 1e3
+                    twos.append(s2)
+                    del st, bufs
+                key = str(n_ranks)
+                shard_pred["per_rank_ms_per_step"][key] = [round(t, 4) for t in ones]
+                shard_pred["per_rank_ms_per_step_two_streams"][key] = [round(t, 4) for t in twos]
+                shard_pred["shard_ms_per_step"][key] = round(max(ones), 4)
+                shard_pred["shard_kernel_ms"][key] = round(max(kern), 4)
+                shard_pred["predicted_speedup"][key] = round(same_job["ms_per_step"] / max(ones), 3)
+                shard_pred["shard_ms_per_step_two_streams"][key] = round(max(twos), 4)
+                shard_pred["predicted_speedup_two_streams"][key] = round(same_job["ms_per_step"] / max(twos), 3)
         except Exception as e:  # noqa: BLE001 -- an extra: must not cost the headline measurement
             torch.cuda.synchronize()
             shard_pred = {"error": repr(e)}

@@ -1,7 +1,7 @@
 // comm.hip -- the multi-GPU exchange of the path-trace job behind the C-ABI (include/brickmap.h "multi-GPU").
 //
 // The reference is single-GPU (no collective anywhere; src/main.cpp:89 computes `multi_gpu` and never uses it).
-// Here every GPU holds a full scene replica and renders the interleaved 16-row bands of the frame that belong to its rank
+// Here every GPU holds a full scene replica and renders the interleaved row bands of the frame that belong to its rank
 // (bm_frame_params band_rows / shard_rank / shard_count) into a PACKED local buffer; one exchange per frame brings the bands
 // to the root:
 //     ncclGroupStart;  root: ncclRecv from every peer straight into one stacked buffer;  peers: ncclSend;  ncclGroupEnd

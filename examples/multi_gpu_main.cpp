@@ -1,5 +1,5 @@
 // examples/multi_gpu_main.cpp -- the reference's main loop (src/main.cpp:100-147) on N GPUs of one node, one process per GPU:
-// every rank holds a full Scene replica, renders the interleaved 16-row bands of the frame that belong to it and hands them to
+// every rank holds a full Scene replica, renders the interleaved 8-row bands of the frame that belong to it and hands them to
 // rank 0 through the C-ABI's RCCL gather (bm_gather_frame: ncclSend / ncclRecv over xGMI + one assembly kernel).
 //   usage: multi_gpu_main <rank> <world> <id_file> [grid_size grid_height width height frames spp out.ppm]
 // Start one process per GPU with the same <id_file> (a path all of them can reach): rank 0 writes the 128-byte communicator
@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
 	}
 	Comm comm(device, rank, world, id);
 
-	State state(width, height, device, Shard{rank, world, 16}); // this rank's bands, packed (main.cpp:102)
+	State state(width, height, device, Shard{rank, world, 8}); // this rank's bands, packed (main.cpp:102)
 	Scene scene(grid_size, grid_height, device);                // a full replica per GPU (main.cpp:104)
 	scene.generate();                                           // main.cpp:105 -- bricks stream in on demand, per GPU
 	camera.position = {grid_size / 2.f, grid_size / 8.f, 0.8f * grid_height};

@@ -80,7 +80,7 @@ public:
 // a rank's rows are packed in increasing y into its State's blit_buffer.  {0, 1} = the whole frame.
 struct Shard {
 	int rank = 0, count = 1;
-	int band_rows = 16; // one row of 16x16-pixel tiles
+	int band_rows = 8;  // rows per band: many bands per rank, so that every rank sees every part of the image (the job is as fast as its slowest rank)
 };
 
 struct State { // state.h:5-34 without the wavefront queues and the GL interop

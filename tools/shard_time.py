@@ -1,5 +1,5 @@
 """Per-rank time of the multi-GPU bench layout on ONE GPU: rank r of N traces all `spp` samples of its H/N rows
-(interleaved 16-row bands, (chunk, sample) work items), consecutive steps on one stream and pipelined over two.
+(interleaved 8-row bands, (chunk, sample) work items), consecutive steps on one stream and pipelined over two.
 usage: shard_time.py [spp=8] [steps=40]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,7 +27,7 @@ def run(st, bufs, N, rank, band, streams):
 base = None
 for N in (1, 2, 4, 8):
     rank = 0
-    band = 16 if N > 1 else H
+    band = bm.dist.DEFAULT_BAND_ROWS if N > 1 else H
     st = bm.State(W, H, device=0, band_rows=band, shard_rank=rank, shard_count=N)
     bufs = [st.blit_buffer, torch.zeros_like(st.blit_buffer)]
     run(st, bufs, N, rank, band, pool[:1])
