@@ -186,7 +186,7 @@ def main():
 
     # rows: the gather of frame i runs on RCCL's stream while frame i+1 is being traced (one gather in flight);
     # samples: ONE sum-reduction after the last step (the per-rank buffers are additive)
-    gatherer = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev, force_collective=True) if by_rows else None
+    gatherer = None  # made below, once the streams are chosen
     reducer = bm.dist.FrameReducer(H, W, device=dev, force_collective=True) if (multi and not by_rows) else None
 
     def pick_streams(count):
@@ -210,8 +210,13 @@ def main():
                 best = (tc, combo)
         return [pool[i] for i in best[1]]
 
+    gather_side = None
     if pipeline > 1:
-        streams = pick_streams(pipeline)
+        # (one stream more for the exchange: it must not share a hardware queue with a render stream, see FrameGatherer)
+        picked = pick_streams(pipeline + (1 if by_rows else 0))
+        streams, gather_side = picked[:pipeline], (picked[pipeline] if by_rows else None)
+    if by_rows:
+        gatherer = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev, force_collective=True, side_stream=gather_side)
 
     gathered = {}  # --verify: the last gathered frame of every accumulation buffer (rank 0)
 
@@ -224,8 +229,11 @@ def main():
         if streams is not None:
             scene.render(cam, params(step), accums[j], stream=streams[j].cuda_stream)
             if gatherer is not None:
-                keep(step - 1, gatherer.finish())  # frame step-1 is complete on rank 0 (while frame `step` is already running on the other stream)
-                streams[j].wait_stream(torch.cuda.current_stream())  # ... before the send / receive buffers are written again
+                # frame step-1 is complete on rank 0 once its gather is (frame `step` is already running on the other stream); only
+                # --verify looks at it here.  start() orders the snapshot behind the previous gather on the frame's own stream.
+                keep(step - 1, gatherer.finish(wait=args.verify))
+                if args.verify:
+                    streams[j].wait_stream(torch.cuda.current_stream())  # (the copy keep() just queued reads the frame the next gather overwrites)
                 with torch.cuda.stream(streams[j]):
                     gatherer.start(accums[j])  # snapshot behind frame `step` on its stream + asynchronous gather of its packed bands
             return accums[j]

@@ -221,7 +221,8 @@ class FrameGatherer:
     force_collective: issue the collective also when the group has a single rank (the 1-rank RCCL dry run of the tests:
     communicator, device buffers, asynchronous work handle -- everything except a second rank)."""
 
-    def __init__(self, height, width, channels=4, band_rows=DEFAULT_BAND_ROWS, dtype=None, device=None, group=None, dst=0, force_collective=False):
+    def __init__(self, height, width, channels=4, band_rows=DEFAULT_BAND_ROWS, dtype=None, device=None, group=None, dst=0, force_collective=False,
+                 side_stream=None):
         import torch
         import torch.distributed as dist
         self.height, self.band_rows, self.group, self.dst = height, band_rows, group, dst
@@ -251,7 +252,11 @@ class FrameGatherer:
         self.local = None
         self.width = width
         if self.comm is not None:
-            self.side = torch.cuda.Stream(device=self.out_device)
+            # side_stream: HIP maps streams onto a few hardware queues, and a queue runs its packets in order -- a gather that waits for
+            # its frame at the head of a queue holds up whatever another stream put behind it there (the NEXT frame, if the render
+            # stream shares that queue: measured, the two-stream pipeline of bench.py then ran no faster than one stream).  A caller
+            # that pipelines frames over several streams passes a stream it has probed to run beside them (bench.py pick_streams).
+            self.side = side_stream if side_stream is not None else torch.cuda.Stream(device=self.out_device)
             self.snap = torch.cuda.Event()
             self.pending = False
 
@@ -263,17 +268,22 @@ class FrameGatherer:
         if not self.collective:
             self.local = local
             return
-        self.send[: local.shape[0]].copy_(local)  # snapshot: the caller may keep accumulating into `local`
         if self.comm is not None:
             assert not self.pending, "finish() the previous gather first"
-            self.snap.record(torch.cuda.current_stream(self.out_device))
+            cur = torch.cuda.current_stream(self.out_device)
+            cur.wait_stream(self.side)  # the previous gather has read `send` (whichever stream its finish() was called on)
+            self.send[: local.shape[0]].copy_(local)  # snapshot: the caller may keep accumulating into `local`
+            self.snap.record(cur)
             self.side.wait_event(self.snap)
             self.comm.gather_frame(self.send, self.out, self.height, self.width, self.band_rows, root=self.dst, stream=self.side.cuda_stream)
             self.pending = True
             return
+        self.send[: local.shape[0]].copy_(local)  # snapshot: the caller may keep accumulating into `local`
         self.work = dist.gather(self.send, gather_list=self.recv, dst=self.dst, group=self.group, async_op=True)
 
-    def finish(self):
+    def finish(self, wait=True):
+        """wait=False: the caller does not touch the frame on the current stream (a render loop that only starts the next gather:
+        start() orders itself behind this one) -- no stream is made to wait."""
         import torch
         if not self.collective:
             out, self.local = self.local, None
@@ -281,7 +291,8 @@ class FrameGatherer:
         if self.comm is not None:
             if not self.pending:
                 return None
-            torch.cuda.current_stream(self.out_device).wait_stream(self.side)  # like Work.wait(): the current stream, not the host
+            if wait:
+                torch.cuda.current_stream(self.out_device).wait_stream(self.side)  # like Work.wait(): the current stream, not the host
             self.pending = False
             return self.out if self.rank == self.dst else None
         if self.work is None:
