@@ -125,6 +125,8 @@ SIGNATURES = {
     "bm_comm_info": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bm_gather_frame": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "bm_reduce_frame": (_i, [_vp, _vp, _vp, C.c_int64, _i, _vp]),
+    "bm_probe_streams": (_i, [_i, _i, C.POINTER(_vp)]),
+    "bm_release_streams": (None, [_i, C.POINTER(_vp)]),
     "bm_comm_barrier": (_i, [_vp, _vp]),
     "bm_comm_selftest": (_i, [_vp, _vp]),
     "bm_debug_assemble_frame": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

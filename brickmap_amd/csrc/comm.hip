@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -103,6 +104,12 @@ __global__ void assemble_frame(const float4* __restrict__ own, const float4* __r
 	const int band = y / band_rows, r = band % world, lrow = (band / world) * band_rows + y % band_rows;
 	const float4* src = r == me ? own : stacked + static_cast<size_t>(r) * max_rows * width;
 	frame[i] = src[static_cast<size_t>(lrow) * width + x];
+}
+
+// bm_probe_streams: one wave that does nothing for `ticks` of the constant 100 MHz clock
+__global__ void spin_kernel(long long ticks) {
+	const long long t0 = wall_clock64();
+	while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
 } // namespace
@@ -234,6 +241,50 @@ int bm_comm_barrier(bm_comm* c, void* hip_stream) {
 	BM_NCCL(R->AllReduce(c->word, c->word, 1, ncclInt, ncclSum, c->comm, stream));
 	BM_HIP(hipStreamSynchronize(stream));
 	return 0;
+}
+
+int bm_probe_streams(int device, int count, void** streams_out) {
+	if (!streams_out || count < 1 || count > 4) { set_error("bad argument"); return BM_EINVAL; }
+	BM_HIP(hipSetDevice(device));
+	const int pool_n = count + 3;
+	hipStream_t pool[8] = {};
+	for (int i = 0; i < pool_n; ++i) {
+		if (hipStreamCreateWithFlags(&pool[i], hipStreamNonBlocking) != hipSuccess) {
+			for (int k = 0; k < i; ++k) (void)hipStreamDestroy(pool[k]);
+			set_error("hipStreamCreate failed");
+			return BM_ESTATE;
+		}
+	}
+	// every combination of `count` candidates: how long do `count` spin kernels (one wave each, ~0.2 ms) take when started together?
+	double best_s = 0.0;
+	unsigned best_mask = 0u;
+	for (unsigned mask = 0; mask < (1u << pool_n); ++mask) {
+		if (__builtin_popcount(mask) != count) continue;
+		double fastest = 0.0;
+		for (int rep = 0; rep < 3; ++rep) {
+			(void)hipDeviceSynchronize();
+			const auto t0 = std::chrono::steady_clock::now();
+			for (int i = 0; i < pool_n; ++i)
+				if (mask & (1u << i)) hipLaunchKernelGGL(bm::spin_kernel, dim3(1), dim3(64), 0, pool[i], 20000ll); // 100 MHz ticks
+			(void)hipDeviceSynchronize();
+			const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+			if (rep == 0 || s < fastest) fastest = s;
+		}
+		if (best_mask == 0u || fastest < best_s * 0.9) { best_s = fastest; best_mask = mask; } // (a later combination must be clearly better)
+	}
+	int n = 0;
+	for (int i = 0; i < pool_n; ++i) {
+		if (best_mask & (1u << i)) streams_out[n++] = pool[i];
+		else (void)hipStreamDestroy(pool[i]);
+	}
+	BM_HIP(hipGetLastError());
+	return 0;
+}
+
+void bm_release_streams(int count, void** streams) {
+	if (!streams) return;
+	for (int i = 0; i < count; ++i)
+		if (streams[i]) { (void)hipStreamDestroy(static_cast<hipStream_t>(streams[i])); streams[i] = nullptr; }
 }
 
 int bm_debug_assemble_frame(int device, const float* own_packed_dev, const float* stacked_dev, float* frame_dev, int height, int width, int band_rows, int world,

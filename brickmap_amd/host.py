@@ -138,6 +138,21 @@ def host_generate_supercell(grid_size, grid_height, sx, sy, sz):
     return idx, bricks[: n.value].copy()
 
 
+def probe_streams(count, device=0):
+    """bm_probe_streams: `count` HIP streams (raw handles, ints) that demonstrably run side by side on `device` -- HIP maps streams
+    onto a few hardware queues, and streams that share one do not overlap.  release_streams() gives them back."""
+    L = _lib.load()
+    arr = (C.c_void_p * int(count))()
+    _lib.check(L.bm_probe_streams(int(device), int(count), arr))
+    return [int(h) for h in arr]
+
+
+def release_streams(handles):
+    L = _lib.load()
+    arr = (C.c_void_p * len(handles))(*handles)
+    L.bm_release_streams(len(handles), arr)
+
+
 class Scene:
     """Scene (Scene.h:7-44): CPU-built world + its residency on ONE GPU.
 

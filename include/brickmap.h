@@ -249,6 +249,14 @@ BM_API int bm_reduce_frame(bm_comm* comm, const float* in_dev, float* out_dev, i
 BM_API int bm_comm_barrier(bm_comm* comm, void* hip_stream);
 /* start-up check of the transport: a grouped send / receive round the ring of ranks and an all-reduce, data verified */
 BM_API int bm_comm_selftest(bm_comm* comm, void* hip_stream);
+/* Streams that demonstrably run side by side.  HIP maps streams onto a few hardware queues and a queue runs its packets in order:
+ * two streams that share a queue do not overlap, and an exchange that waits for its frame at the head of a queue holds up whatever
+ * another stream queued behind it.  A host that pipelines frames over two streams with bm_gather_frame on a third (INTEGRATION.md 1a;
+ * measured: 0.98 against 1.20 ms per 1/8-shard step) takes its streams from here: `count` (1 ... 4) non-blocking streams on `device`,
+ * picked from a few more candidates by timing a short spin kernel on every combination.  The caller owns them
+ * (bm_release_streams, or hipStreamDestroy on each). */
+BM_API int bm_probe_streams(int device, int count, void** streams_out);
+BM_API void bm_release_streams(int count, void** streams);
 /* test door: the root's assembly kernel alone, on one GPU -- frame row y <- packed row of rank (y / band_rows) % world, taken from
  * own_packed_dev for rank `me` and from stacked_dev (world x max_rows x width float4, rank-major) for everybody else */
 BM_API int bm_debug_assemble_frame(int device, const float* own_packed_dev, const float* stacked_dev, float* frame_dev, int height, int width,

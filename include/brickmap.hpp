@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
+#include <vector>
 
 #include "brickmap.h"
 
@@ -200,6 +201,14 @@ inline void gather_frame(Comm& comm, const State& state, vec4* frame_on_root, in
 	BM_CHECKED(bm_gather_frame(comm.handle, reinterpret_cast<const float*>(state.blit_buffer), reinterpret_cast<float*>(frame_on_root),
 							   static_cast<int>(state.screen_height), static_cast<int>(state.screen_width), state.shard.count > 1 ? state.shard.band_rows : static_cast<int>(state.screen_height),
 							   root, nullptr));
+}
+
+// Streams that run side by side (bm_probe_streams): for a host that pipelines frames over two streams with the exchange on a third.
+// The HIP stream handles come back as void*; the caller releases them with bm_release_streams (or hipStreamDestroy).
+inline std::vector<void*> probe_streams(int device, int count) {
+	std::vector<void*> streams(static_cast<size_t>(count), nullptr);
+	BM_CHECKED(bm_probe_streams(device, count, streams.data()));
+	return streams;
 }
 
 // The reference's own schedule.  RayQueue* queue / queue2 and ShadowQueue* shadowQueue of the reference signature

@@ -1126,3 +1126,33 @@ print("DIGEST", h.hexdigest())
         assert r.returncode == 0, r.stderr[-2000:]
         digests[v or "rule"] = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
     assert len(set(digests.values())) == 1, digests
+
+
+@pytest.mark.gpu
+def test_probed_streams_overlap_frames(bm, torch_cuda, scene256):
+    """bm_probe_streams hands out streams that demonstrably run side by side: distinct handles, and consecutive frames on two of them
+    (one accumulation buffer each) take clearly less time than the same frames on one -- the next frame's workgroups fill the slots
+    the previous one frees while it works its last paths off."""
+    import time
+    torch = torch_cuda
+    handles = bm.probe_streams(3, device=0)
+    try:
+        assert len(set(handles)) == 3 and all(handles)
+        cam = bm.Camera(position=(128.0, 32.0, 205.0), horizontal_angle=0.8, vertical_angle=-0.5).update()
+        W, H, n = 960, 540, 40
+        bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+
+        def run(streams):
+            best = 1e9
+            for rep in range(3):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for i in range(n):
+                    scene256.render(cam, bm.FrameParams(W, H, spp=1, sample_base=i, max_bounces=3), bufs[i % len(streams)], stream=streams[i % len(streams)])
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t)
+            return best
+        one, two = run(handles[:1]), run(handles[:2])
+        assert two < 0.95 * one, (one, two)
+    finally:
+        bm.release_streams(handles)
