@@ -71,6 +71,7 @@ struct FrameConstants {
 	int band_rows, shard_rank, shard_count, local_rows;
 	// launch geometry
 	int tiles_x, tiles_y; // 16x16-pixel tiles covering this shard's rows
+	int xcd_handout;      // 1: XCD-aware hand-out (trace.hip refill: 256x256-pixel super-tiles dealt to the eight XCDs' counters); big frames only
 	int refill_min;       // a wave takes new work items once this many of its lanes are idle (frame_constants(): by the length of an item)
 };
 

@@ -85,7 +85,9 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #else
 #define BM_TIMED DBG
 #endif
-template <bool DBG>
+// XCD: the XCD-aware hand-out (FrameConstants::xcd_handout; big frames) -- an instantiation of its own, so that the hand-out code of
+// the headline kernel stays what it was (as a run-time branch it cost config 2 0.5-1 %)
+template <bool DBG, bool XCD = false>
 // (the instrumented variant carries hit records and counters: it gets the registers instead of the occupancy)
 __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, float4* __restrict__ accum,
 												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters,
@@ -136,7 +138,15 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	constexpr uint32_t kCounters = BM_WORK_COUNTERS, kCounterStride = 32; // one 128-byte line per counter
 	// (the wave index is the same in all 64 lanes; saying so keeps everything derived from it -- the counter in use, `work_left`,
 	// the loop's exit conditions -- in scalar registers and the scheduler loop's branches scalar)
-	int my_counter = static_cast<int>((blockIdx.x * 4u + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)))) % kCounters);
+	// XCD-aware hand-out (FrameConstants::xcd_handout, big frames): the image is cut into super-tiles of kXcdTiles x kXcdTiles tiles
+	// (256 x 256 pixels), super-tile st belongs to counter st % 8, and a wave starts on the counter of ITS XCD -- workgroups are
+	// dispatched round-robin over the 8 XCDs, so blockIdx % 8 names the L2 -- so that the rays of neighbouring pixels, which read
+	// the same field rows, index words and bricks, are traced behind ONE L2 instead of all eight; a wave whose counter is used up
+	// helps the next one.  Otherwise: groups of four chunks dealt to the counters, every wave of a workgroup on its own counter.
+	constexpr uint32_t kXcdTiles = 16u, kStChunks = kXcdTiles * kXcdTiles * 16u;
+	constexpr bool xcd_handout = XCD;
+	int my_counter = xcd_handout ? static_cast<int>(blockIdx.x % kCounters)
+								 : static_cast<int>((blockIdx.x * 4u + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)))) % kCounters);
 	int counters_done = 0;
 	// hang guard only (NaN directions): no wave needs more scheduler rounds than this
 	const long long round_budget = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fc.spp) + 1) * (fc.max_bounces + 2) *
@@ -171,10 +181,12 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			uint32_t base = 0;
 			if (lane == 0) base = atomicAdd(work_counter + my_counter * kCounterStride, static_cast<uint32_t>(want));
 			base = __builtin_amdgcn_readfirstlane(base);
-			const uint32_t total_groups = (total_chunks + 3u) >> 2;
-			const uint32_t my_groups = total_groups > static_cast<uint32_t>(my_counter)
-										   ? (total_groups - static_cast<uint32_t>(my_counter) + kCounters - 1u) / kCounters : 0u;
-			const uint32_t my_tickets = my_groups * 4u * items_per_chunk; // consecutive tickets = the samples of one chunk
+			// units dealt to the counters: groups of four chunks, or whole super-tiles
+			const uint32_t st_x = (static_cast<uint32_t>(fc.tiles_x) + kXcdTiles - 1u) / kXcdTiles, st_y = (static_cast<uint32_t>(fc.tiles_y) + kXcdTiles - 1u) / kXcdTiles;
+			const uint32_t total_units = xcd_handout ? st_x * st_y : (total_chunks + 3u) >> 2;
+			const uint32_t my_units = total_units > static_cast<uint32_t>(my_counter)
+										  ? (total_units - static_cast<uint32_t>(my_counter) + kCounters - 1u) / kCounters : 0u;
+			const uint32_t my_tickets = my_units * (xcd_handout ? kStChunks : 4u) * items_per_chunk; // consecutive tickets = the samples of one chunk
 			const uint32_t counter_now = static_cast<uint32_t>(my_counter);
 			if (base + want >= my_tickets) { // this counter is used up: move to the next one (helping out), or finish
 				my_counter = (my_counter + 1) % static_cast<int>(kCounters);
@@ -185,11 +197,26 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				const uint32_t item = base + static_cast<uint32_t>(rank / BM_ITEM_LANES);
 				const uint32_t ticket = item / items_per_chunk, item_sub = item - ticket * items_per_chunk;
 				const uint32_t item_sample = item_sub / kParts, part = item_sub % kParts; // (kParts == 1: part 0)
-				const uint32_t chunk = ((ticket >> 2) * kCounters + counter_now) * 4u + (ticket & 3u);
-				if (item < my_tickets && chunk < total_chunks) {
-					const uint32_t tile = chunk >> 4, k = chunk & 15u;
-					const int tile_x = static_cast<int>(tile % static_cast<uint32_t>(fc.tiles_x));
-					const int tile_y = static_cast<int>(tile / static_cast<uint32_t>(fc.tiles_x));
+				uint32_t k;
+				int tile_x, tile_y;
+				bool in_frame;
+				if (xcd_handout) {
+					const uint32_t st = (ticket / kStChunks) * kCounters + counter_now, in_st = ticket % kStChunks;
+					const uint32_t tw = in_st >> 4;
+					k = in_st & 15u;
+					const uint32_t st_row = st / st_x;
+					tile_x = static_cast<int>((st - st_row * st_x) * kXcdTiles + tw % kXcdTiles);
+					tile_y = static_cast<int>(st_row * kXcdTiles + tw / kXcdTiles);
+					in_frame = tile_x < fc.tiles_x && tile_y < fc.tiles_y;
+				} else {
+					const uint32_t chunk = ((ticket >> 2) * kCounters + counter_now) * 4u + (ticket & 3u);
+					const uint32_t tile = chunk >> 4;
+					k = chunk & 15u;
+					tile_x = static_cast<int>(tile % static_cast<uint32_t>(fc.tiles_x));
+					tile_y = static_cast<int>(tile / static_cast<uint32_t>(fc.tiles_x));
+					in_frame = chunk < total_chunks;
+				}
+				if (item < my_tickets && in_frame) {
 					const int cx = static_cast<int>((k & 1u) | ((k >> 1) & 2u)), cy = static_cast<int>(((k >> 1) & 1u) | ((k >> 2) & 2u));
 					const uint32_t q = part * BM_ITEM_LANES + (static_cast<uint32_t>(rank) % BM_ITEM_LANES); // pixel of the 4x4 chunk
 					const int x = tile_x * 16 + cx * 4 + static_cast<int>(q & 3u);
@@ -561,17 +588,21 @@ void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameCo
 	if (chunks <= 0) return;
 	long long blocks = (chunks + 15) / 16; // never more workgroups than 64-pixel groups
 	if (blocks > resident_blocks) blocks = resident_blocks;
-	if (instrumented)
-		hipLaunchKernelGGL(trace_paths<true>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc_dev, reinterpret_cast<float4*>(accum), dbg,
-						   counters, work_counter);
-	else
+	const bool xcd = fc.xcd_handout != 0;
+	float4* const acc4 = reinterpret_cast<float4*>(accum);
+	const dim3 grid(static_cast<unsigned>(blocks)), block(256);
 #ifdef BM_PHASE_TIMING
-		hipLaunchKernelGGL(trace_paths<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc_dev, reinterpret_cast<float4*>(accum), nullptr,
-						   counters, work_counter);
+	DeviceCounters* const plain_counters = counters; // profiling build: the plain kernel reports its phase timers too
 #else
-		hipLaunchKernelGGL(trace_paths<false>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, sc, fc_dev, reinterpret_cast<float4*>(accum), nullptr,
-						   nullptr, work_counter);
+	DeviceCounters* const plain_counters = nullptr;
 #endif
+	if (instrumented) {
+		if (xcd) hipLaunchKernelGGL((trace_paths<true, true>), grid, block, 0, stream, sc, fc_dev, acc4, dbg, counters, work_counter);
+		else hipLaunchKernelGGL((trace_paths<true, false>), grid, block, 0, stream, sc, fc_dev, acc4, dbg, counters, work_counter);
+	} else {
+		if (xcd) hipLaunchKernelGGL((trace_paths<false, true>), grid, block, 0, stream, sc, fc_dev, acc4, nullptr, plain_counters, work_counter);
+		else hipLaunchKernelGGL((trace_paths<false, false>), grid, block, 0, stream, sc, fc_dev, acc4, nullptr, plain_counters, work_counter);
+	}
 }
 
 void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const uint32_t* indices_queue, uint32_t* arena, uint32_t count,

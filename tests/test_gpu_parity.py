@@ -1092,8 +1092,9 @@ def test_kslot_counters(bm, torch_cuda, scene256, world256, orc):
 
 
 @pytest.mark.gpu
-def test_refill_threshold_changes_nothing_but_time(bm, torch_cuda, tmp_path):
-    """FrameConstants::refill_min (scene.cpp frame_constants: 16 / 8 / 4 idle lanes by the samples per work item, BM_REFILL_MIN
+def test_refill_threshold_and_handout_order_change_nothing_but_time(bm, torch_cuda, tmp_path):
+    """FrameConstants::xcd_handout (256x256-pixel super-tiles dealt to the XCDs' counters: big frames by rule, BM_XCD_HANDOUT forces it) and
+    FrameConstants::refill_min (scene.cpp frame_constants: 16 / 8 / 4 idle lanes by the samples per work item, BM_REFILL_MIN
     overrides it per process) decides WHEN a wave takes new pixels, never what a path computes: the same frames -- 1, 2 and 5 samples
     per pixel, pixel items and (chunk, sample) items' hit digests -- bit for bit under the rule and under forced thresholds."""
     code = r'''
@@ -1117,10 +1118,15 @@ print("DIGEST", h.hexdigest())
     import subprocess
     import sys
     digests = {}
-    for v in ("", "1", "4", "16", "33", "64"):
+    for v in ("", "1", "4", "16", "33", "64", "xcd", "xcd4"):
         env = dict(os.environ)
         env.pop("BM_REFILL_MIN", None)
-        if v:
+        env.pop("BM_XCD_HANDOUT", None)
+        if v.startswith("xcd"):  # the XCD-aware hand-out (big frames by rule) forced onto these small ones: another order, the same pixels
+            env["BM_XCD_HANDOUT"] = "1"
+            if v[3:]:
+                env["BM_REFILL_MIN"] = v[3:]
+        elif v:
             env["BM_REFILL_MIN"] = v
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -12,10 +12,14 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "brickmap_amd", "csrc")
-KERNEL = "_ZN2bm11trace_pathsILb0E"
+KERNELS = ("_ZN2bm11trace_pathsILb0ELb0E", "_ZN2bm11trace_pathsILb0ELb1E")  # the plain instantiation, and the one with the XCD-aware hand-out
 
 
-def test_production_kernel_keeps_its_register_budget_and_its_shape():
+import pytest
+
+
+@pytest.mark.parametrize("KERNEL", KERNELS)
+def test_production_kernel_keeps_its_register_budget_and_its_shape(KERNEL):
     subprocess.check_call(["make", "-s", "-C", CSRC, "asm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     usage = open(os.path.join(CSRC, "build", "resource_usage.txt")).read()
     block = usage[usage.index(KERNEL):]

@@ -18,7 +18,7 @@ tot = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for f in glob.glob("$OUT/p*/p_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "trace_paths<false>" not in k: continue
+        if "trace_paths<false," not in k: continue
         tot[r["Counter_Name"]]["v"] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 disp = 4
 for c in sorted(tot): print(c, tot[c]["v"] / disp)
