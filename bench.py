@@ -46,10 +46,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # what bounds trace_paths on each workload (profiles/r0x_pmc_summary_<workload>.json, profiles/r03_fetch_calibration.txt)
 LIMITER = {
     "config2": "VALU issue: the vector pipes are busy for >= 85 % of the launch with ~20 of 64 lanes active per instruction; the scene (93 MiB) stays in L2 / Infinity Cache",
-    "config3": "VALU issue, with 0.6 G L2 sector misses per launch (TCC hit 61 %)",
-    "config5": "two limits at once: 41.5 G single-sector (64 B) read requests/s = 0.86 of the 48 G/s the fabric sustains for random sectors (3.1 TB/s, not the 8 TB/s byte peak), and VALU issue (vector pipes full at ~18 of 64 lanes per instruction)",
+    "config3": "VALU issue, with 0.63 G single-sector reads reaching the fabric per launch (TCC hit 64 %)",
+    "config5": "VALU issue (85 G wave instructions at ~19 of 64 lanes: the vector pipes are full); with the XCD-aware hand-out of big frames the fabric sees 30.5 G single-sector "
+               "(64 B) read requests/s = 0.63 of the 48 G/s it sustains for random sectors (0.92 before: a third less traffic bought 3 % of time)",
 }
-PROFILE_ROUNDS = ("r04", "r03")  # profiles/<round>_pmc_summary_<workload>.json is where roofline.traffic comes from (newest first; the kernel is unchanged since round 2)
+PROFILE_ROUNDS = ("r04", "r03")  # profiles/<round>_pmc_summary_<workload>.json is where roofline.traffic comes from (newest first)
 
 
 def workload(name):
