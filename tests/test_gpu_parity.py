@@ -1104,10 +1104,10 @@ import numpy as np, torch, brickmap_amd as bm
 scene = bm.Scene(256, 256, device=0).generate().preload_all()
 cam = bm.Camera(position=(128.0, 40.0, 200.0), horizontal_angle=0.9, vertical_angle=-0.6).update()
 h = hashlib.sha256()
-for spp, flags in ((1, 0), (2, 0), (5, 0), (3, bm.BM_FLAG_SAMPLE_ITEMS)):
-    p = bm.FrameParams(97, 61, spp=spp, max_bounces=3, flags=flags)
-    acc = torch.zeros((61, 97, 4), dtype=torch.float32, device="cuda:0")
-    dbg = torch.zeros((61, 97, 8), dtype=torch.int32, device="cuda:0")
+for W, H, spp, flags in ((97, 61, 1, 0), (97, 61, 2, 0), (97, 61, 5, 0), (97, 61, 3, bm.BM_FLAG_SAMPLE_ITEMS), (700, 500, 1, 0)):  # (the last: 3 x 2 super-tiles, cut by the frame's edge)
+    p = bm.FrameParams(W, H, spp=spp, max_bounces=3, flags=flags)
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    dbg = torch.zeros((H, W, 8), dtype=torch.int32, device="cuda:0")
     scene.render(cam, p, acc, debug=dbg)
     torch.cuda.synchronize()
     h.update(dbg.cpu().numpy().tobytes())
