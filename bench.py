@@ -488,8 +488,8 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
             **pmc_traffic(args.workload),
-            # (the plain instantiation; big frames -- 65536 tiles and more, scene.cpp frame_constants -- take the XCD-aware hand-out)
-            "kernel": "bm::trace_paths<false, true>" if ((W + 15) // 16) * ((state.local_rows + 15) // 16) >= 65536 and os.environ.get("BM_XCD_HANDOUT") != "0" or os.environ.get("BM_XCD_HANDOUT") == "1" else "bm::trace_paths<false, false>",
+            # (the plain instantiation; big frames -- 32000 tiles and more, scene.cpp frame_constants -- take the XCD-aware hand-out)
+            "kernel": "bm::trace_paths<false, true>" if ((W + 15) // 16) * ((state.local_rows + 15) // 16) >= 32000 and os.environ.get("BM_XCD_HANDOUT") != "0" or os.environ.get("BM_XCD_HANDOUT") == "1" else "bm::trace_paths<false, false>",
             "kernel_ms_avg": round(float(np.mean(kernel_ms)), 4),
             "algorithmic_bytes_per_launch": alg_bytes / args.steps,
             "bytes_per_actual_ray": round(alg_bytes / max(actual_rays, 1), 1),

@@ -120,9 +120,9 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp,
 	const int samples_per_item = (fp->flags & BM_FLAG_SAMPLE_ITEMS) ? 1 : fp->spp;
 	fc->refill_min = samples_per_item >= 4 ? 4 : (samples_per_item >= 2 ? 8 : 16);
 	// XCD-aware hand-out: neighbouring rays behind ONE L2 instead of all eight.  Pays where the scene does not fit the caches and the
-	// frame has enough 256x256-pixel super-tiles for eight even shares (8K: 510) -- config 5 115.0 -> 111.5 ms; on a 1080p frame
-	// (40 super-tiles) the shares are too uneven: +8 % (profiles/r04_xcd_handout.txt)
-	fc->xcd_handout = (static_cast<long long>(fc->tiles_x) * fc->tiles_y >= 65536) ? 1 : 0;
+	// frame has enough 256x256-pixel super-tiles for eight even shares (8K: 510, 4K: 135) -- config 5 115.0 -> 111.5 ms, config 3
+	// 24.05 -> 23.90; on a 1080p frame (40 super-tiles) the shares are too uneven: +8 % (profiles/r04_xcd_handout.txt)
+	fc->xcd_handout = (static_cast<long long>(fc->tiles_x) * fc->tiles_y >= 32000) ? 1 : 0;
 	static const int xcd_override = [] { const char* e = std::getenv("BM_XCD_HANDOUT"); return e ? std::atoi(e) : -1; }(); // tuning runs / tests
 	if (xcd_override == 0 || xcd_override == 1) fc->xcd_handout = xcd_override;
 	static const int refill_override = [] { const char* e = std::getenv("BM_REFILL_MIN"); return e ? std::atoi(e) : 0; }(); // tuning runs
