@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # what bounds trace_paths on each workload (profiles/r0x_pmc_summary_<workload>.json, profiles/r03_fetch_calibration.txt)
 LIMITER = {
     "config2": "VALU issue: the vector pipes are busy for >= 85 % of the launch with ~20 of 64 lanes active per instruction; the scene (93 MiB) stays in L2 / Infinity Cache",
-    "config3": "VALU issue, with 0.63 G single-sector reads reaching the fabric per launch (TCC hit 64 %)",
+    "config3": "VALU issue, with 0.40 G single-sector reads reaching the fabric per launch (TCC hit 75 %; XCD-aware hand-out)",
     "config5": "VALU issue (85 G wave instructions at ~19 of 64 lanes: the vector pipes are full); with the XCD-aware hand-out of big frames the fabric sees 30.5 G single-sector "
                "(64 B) read requests/s = 0.63 of the 48 G/s it sustains for random sectors (0.92 before: a third less traffic bought 3 % of time)",
 }
