@@ -97,6 +97,9 @@ def main():
                     help="fused = one persistent kernel tracing complete paths (the product's default); wavefront = the "
                          "reference's own queue schedule, one segment of every path in flight per step (N = 1 only)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher: start the N ranks ourselves (one process per GPU; rank 0 prints the line)
+        raise SystemExit(self_launch(args.gpus))
     if args.pipeline is None:
         args.pipeline = 1 if (args.gpus == 1 and os.environ.get("BM_BENCH_FORCE_DIST") != "1") else 2
 
@@ -219,6 +222,14 @@ def main():
     if by_rows:
         gatherer = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev, force_collective=True, side_stream=gather_side)
 
+    if multi and not share_gpu and os.environ.get("BM_DIST_TORCH", "0") != "1":
+        # the exchange of an RCCL group is the C-ABI's (bm_comm_create + bm_comm_selftest ran inside the constructor above, on every
+        # rank): a run that silently fell back to torch.distributed would not be the product's path -- fail loudly, with RCCL's words
+        ex = gatherer if gatherer is not None else reducer
+        if getattr(ex, "comm", None) is None:
+            raise SystemExit(f"bench.py rank {rank}/{world}: the C-ABI RCCL exchange failed its start-up self-test (bm_comm_create / bm_comm_selftest): "
+                             f"{bm.dist.last_comm_error or 'no error text'}")
+
     gathered = {}  # --verify: the last gathered frame of every accumulation buffer (rank 0)
 
     def keep(step, frame):
@@ -279,7 +290,20 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     kernel_ms = scene.render_times(args.steps)  # HIP events on the launch stream, one pair per launch
+    ranks_info = None
     if multi:
+        # every rank's own clock and device, for the line: an imbalance (or two ranks on one GPU) shows up in SCALE_rNN.json
+        ex = gatherer if gatherer is not None else reducer
+        comm_world = ex.comm.info()[1] if getattr(ex, "comm", None) is not None else None
+        mine = {"rank": rank, "device": torch.cuda.get_device_name(local_rank), "device_index": local_rank,
+                "pci_bus_id": getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None),
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "kernel_ms_avg": round(float(np.mean(kernel_ms)), 4)}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        ranks_info = {"process_group_world": dist.get_world_size(), "process_group_backend": dist.get_backend(),
+                      "communicator_world": comm_world,  # bm_comm_info of the C-ABI communicator the frames travelled through (None: torch.distributed's exchange)
+                      "ms_per_step": [e["ms_per_step"] for e in every], "kernel_ms_avg": [e["kernel_ms_avg"] for e in every],
+                      "devices": [f'{e["device"]} #{e["device_index"]}' + (f' {e["pci_bus_id"]}' if e["pci_bus_id"] is not None else "") for e in every]}
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -507,6 +531,8 @@ def main():
 
     if target4 is not None:
         out["north_star_4spp"] = target4
+    if ranks_info is not None:
+        out["ranks"] = ranks_info
     if verified is not None:
         out["verified_against_single_gpu"] = verified
     if same_job is not None:
@@ -518,6 +544,25 @@ def main():
     print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()
+
+
+def self_launch(n_gpus):
+    """Re-run this command line under torch.distributed.run: one rank per GPU on this node, static rendezvous on 127.0.0.1 (the
+    container's hostname may not resolve), a free port, HSA_ENABLE_IPC_MODE_LEGACY=0 for RCCL's dmabuf IPC.  The children's
+    stdout / stderr pass through, so rank 0's JSON line is this process's; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["BM_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def bench_wavefront(args, bm, torch, np, scene, cam, accum, W, H, max_bounces, n_super, G, streaming, build_s):

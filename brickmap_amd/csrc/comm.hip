@@ -43,6 +43,8 @@ struct Rccl {
 	decltype(&ncclReduce) Reduce = nullptr;
 	decltype(&ncclAllReduce) AllReduce = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	decltype(&ncclCommCount) CommCount = nullptr;       // optional: bm_comm_info asks the library itself where it can
+	decltype(&ncclCommUserRank) CommUserRank = nullptr; // optional
 };
 
 Rccl bind_rccl() {
@@ -58,7 +60,7 @@ Rccl bind_rccl() {
 	if (api.lib) {
 #define BM_SYM(name) api.name = reinterpret_cast<decltype(api.name)>(dlsym(api.lib, "nccl" #name))
 		BM_SYM(GetUniqueId); BM_SYM(CommInitRank); BM_SYM(CommDestroy); BM_SYM(GroupStart); BM_SYM(GroupEnd);
-		BM_SYM(Send); BM_SYM(Recv); BM_SYM(Reduce); BM_SYM(AllReduce); BM_SYM(GetErrorString);
+		BM_SYM(Send); BM_SYM(Recv); BM_SYM(Reduce); BM_SYM(AllReduce); BM_SYM(GetErrorString); BM_SYM(CommCount); BM_SYM(CommUserRank);
 #undef BM_SYM
 		if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Send || !api.Recv || !api.Reduce ||
 			!api.AllReduce || !api.GetErrorString) {
@@ -171,10 +173,20 @@ void bm_comm_destroy(bm_comm* c) {
 	delete c;
 }
 
+int bm_comm_available(void) { return bm::rccl() ? 1 : 0; }
+
 int bm_comm_info(bm_comm* c, int* rank, int* world) {
 	if (!c) { set_error("null communicator"); return BM_EINVAL; }
-	if (rank) *rank = c->rank;
-	if (world) *world = c->world;
+	// what the LIBRARY says about the communicator (ncclCommUserRank / ncclCommCount), so that "did RCCL see N ranks" has an answer
+	// that does not come from the caller's own arguments; a transport without those two entry points reports what it was created with
+	bm::Rccl* R = bm::rccl();
+	int r = c->rank, w = c->world;
+	if (R && R->CommCount && R->CommUserRank && c->comm) {
+		BM_NCCL(R->CommUserRank(c->comm, &r));
+		BM_NCCL(R->CommCount(c->comm, &w));
+	}
+	if (rank) *rank = r;
+	if (world) *world = w;
 	return 0;
 }
 

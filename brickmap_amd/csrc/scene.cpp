@@ -127,6 +127,24 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp,
 	if (xcd_override == 0 || xcd_override == 1) fc->xcd_handout = xcd_override;
 	static const int refill_override = [] { const char* e = std::getenv("BM_REFILL_MIN"); return e ? std::atoi(e) : 0; }(); // tuning runs
 	if (refill_override >= 1 && refill_override <= 64) fc->refill_min = refill_override;
+	// The hand-out counts tickets in 32 bits (trace.hip: `my_tickets`, `base + want`).  The busiest counter owns a 1/8 share of the
+	// units -- groups of four chunks, or 256x256-pixel super-tiles of 4096 chunks -- times 16 tickets per chunk and, with (chunk,
+	// sample) items, per sample; every wave may overshoot a used-up counter once by up to 64.  Refuse what would wrap.
+	{
+		const long long tiles = static_cast<long long>(fc->tiles_x) * fc->tiles_y;
+		const long long per_chunk = 16ll * ((fp->flags & BM_FLAG_SAMPLE_ITEMS) ? std::max(fp->spp, 1) : 1);
+		long long share;
+		if (fc->xcd_handout) {
+			const long long st = static_cast<long long>((fc->tiles_x + 15) / 16) * ((fc->tiles_y + 15) / 16);
+			share = ((st + 7) / 8) * 4096ll * per_chunk;
+		} else {
+			share = ((tiles * 4 + 7) / 8) * 4ll * per_chunk;
+		}
+		if (share >= (1ll << 32) - (1ll << 24)) {
+			set_error("frame too large for the 32-bit ticket counters: tiles x samples per launch (lower spp per call, or render row-band shards)");
+			return BM_EINVAL;
+		}
+	}
 	return 0;
 }
 
@@ -914,6 +932,11 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 	DeviceCounters* const counters_arg = (fp->flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr;
 #endif
 	if (kslot_default_ || (fp->flags & BM_FLAG_KSLOT)) {
+		// the K-slot schedule packs a path's sample index (16 bits) and bounce count (4 bits) into one word (trace_k.hip path flags)
+		if (fp->max_bounces > 15 || fp->spp > 65535) {
+			set_error("K-slot schedule: max_bounces is limited to 15 and spp to 65535 per launch (the default schedule has no such limit)");
+			return BM_EINVAL;
+		}
 		// K-slot schedule: the launch keeps its path records in a scratch buffer of the stream it runs on
 		const int resident = compute_units_ * blocks_per_cu_k_[instrumented ? 1 : 0];
 		const size_t need = trace_k_scratch_bytes(instrumented, resident);

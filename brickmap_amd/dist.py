@@ -32,6 +32,7 @@ import numpy as np
 # bands the slowest of eight ranks takes 1.280 ms per step against 1.232 (the job is as fast as its slowest rank), with 4-row bands 1.243
 DEFAULT_BAND_ROWS = 8
 _cache = {}  # receive buffers / row indices, keyed by the gather's shape (per-frame gathers reuse them)
+last_comm_error = None  # why _make_comm last gave up on the C-ABI exchange (this rank's own error text, or that another rank failed)
 
 
 class Comm:
@@ -84,13 +85,19 @@ class Comm:
         self._check(self._L.bm_reduce_frame(self.handle, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()) if dst is not None else None,
                                             int(src.numel()), int(root), C.c_void_p(stream)))
 
+    def info(self):
+        """bm_comm_info: (rank, world) as the communicator itself reports them (ncclCommUserRank / ncclCommCount)."""
+        r, w = C.c_int(-1), C.c_int(-1)
+        self._check(self._L.bm_comm_info(self.handle, C.byref(r), C.byref(w)))
+        return int(r.value), int(w.value)
+
     def barrier(self, stream=None):
         import torch
-        self._check(self._L.bm_comm_barrier(self.handle, C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)))
+        self._check(self._L.bm_comm_barrier(self.handle, C.c_void_p(stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream)))
 
     def selftest(self, stream=None):
         import torch
-        self._check(self._L.bm_comm_selftest(self.handle, C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)))
+        self._check(self._L.bm_comm_selftest(self.handle, C.c_void_p(stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream)))
 
     def close(self):
         if getattr(self, "handle", None):
@@ -120,12 +127,17 @@ def _make_comm(device_index, group):
 
     # 1. can every rank bind the library at all?  (A rank that failed later, inside from_process_group, would leave the others
     #    waiting in the id's broadcast or in ncclCommInitRank: settle it while nobody depends on anybody yet.)
+    global last_comm_error
+    last_comm_error = None
     why = None
     try:
-        Comm.unique_id()
+        from . import _lib
+        if not _lib.load().bm_comm_available():  # binds the library, starts nothing (ncclGetUniqueId would start a bootstrap listener per call)
+            why = "RCCL library (librccl.so.1) not found"
     except Exception as e:  # noqa: BLE001
         why = e
     if not agreed(0 if why else 1):
+        last_comm_error = str(why) if why is not None else "another rank could not bind the RCCL library"
         if why is not None:
             print(f"brickmap_amd.dist: C-ABI RCCL exchange unavailable ({why}); using torch.distributed", file=sys.stderr)
         return None
@@ -136,8 +148,11 @@ def _make_comm(device_index, group):
         comm.selftest()
     except Exception as e:  # noqa: BLE001 -- anything at all: the render must not depend on it
         ok = 0
+        last_comm_error = str(e)
         print(f"brickmap_amd.dist: C-ABI RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
     if not agreed(ok):
+        if last_comm_error is None:
+            last_comm_error = "another rank's bm_comm_create / bm_comm_selftest failed"
         if comm is not None:
             comm.close()
         return None
@@ -341,14 +356,17 @@ class FrameReducer:
         if not self.collective:
             self.local = local
             return
-        self.buf.copy_(local)  # snapshot: the caller may keep accumulating into `local`
         if self.comm is not None:
             assert not self.pending, "finish() the previous reduction first"
-            self.snap.record(torch.cuda.current_stream(self.out_device))
+            cur = torch.cuda.current_stream(self.out_device)
+            cur.wait_stream(self.side)  # the previous reduction has read / written `buf` (whichever stream its finish() was called on)
+            self.buf.copy_(local)  # snapshot: the caller may keep accumulating into `local`
+            self.snap.record(cur)
             self.side.wait_event(self.snap)
             self.comm.reduce_frame(self.buf, self.buf, root=self.dst, stream=self.side.cuda_stream)  # in place, like dist.reduce
             self.pending = True
             return
+        self.buf.copy_(local)  # snapshot: the caller may keep accumulating into `local`
         self.work = dist.reduce(self.buf, dst=self.dst, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):

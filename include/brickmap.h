@@ -237,7 +237,11 @@ BM_API int bm_comm_unique_id(void* id128);
 /* ncclCommInitRank on `device`: collective over all `world` ranks (one process or thread per GPU) */
 BM_API int bm_comm_create(int device, int rank, int world, const void* id128, bm_comm** out);
 BM_API void bm_comm_destroy(bm_comm* comm);
+/* rank and size AS THE LIBRARY REPORTS THEM (ncclCommUserRank / ncclCommCount) -- "did RCCL see N ranks" -- or, for a transport
+ * without those entry points, what the communicator was created with */
 BM_API int bm_comm_info(bm_comm* comm, int* rank, int* world);
+/* 1 if the RCCL library can be bound in this process (dlopen + the entry points), 0 if not; starts nothing, allocates nothing */
+BM_API int bm_comm_available(void);
 /* packed_dev: this rank's bm_local_rows x width float4 (what bm_render_frame accumulated for its shard); frame_dev: height x width
  * float4 on the root (ignored elsewhere).  Enqueued on hip_stream: ordered behind the frame that produced packed_dev; the host
  * does not wait.  The row-to-rank map is that of bm_frame_params: row y belongs to rank (y / band_rows) % world. */

@@ -1050,6 +1050,73 @@ def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda, tmp_path):
         port += 1
 
 
+def test_long_paths_and_schedule_limits(bm, orc, torch_cuda, scene256, world256):
+    """max_bounces = 16 (17 segments per path): the default schedule has no limit and matches the oracle; the K-slot schedule packs
+    the bounce count into 4 bits and the sample index into 16 and must REFUSE what it cannot represent (BM_EINVAL) instead of
+    rendering a wrong image; and a frame whose tickets would wrap the 32-bit hand-out counters is refused as well."""
+    import copy
+    torch = torch_cuda
+    cam, ocam = cameras(bm, orc, 256)
+    W, H = 96, 64
+    p = bm.FrameParams(W, H, spp=1, max_bounces=16)
+    os.environ["BM_TEST_KSLOT"] = "0"
+    try:
+        a, dbg = gpu_render(bm, torch, scene256, cam, p)
+    finally:
+        os.environ.pop("BM_TEST_KSLOT", None)
+    oacc, odbg, _, _ = world256.render(ocam, orc.make_frame(W, H, spp=1, max_bounces=16))
+    assert np.array_equal(dbg, odbg)
+    assert_radiance(a, oacc)
+    assert int((dbg[..., 6] & 0xFFFF).max()) > 5  # some paths really are longer than the K-slot schedule's old silent limit allows to matter
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    for bad in (bm.FrameParams(W, H, spp=1, max_bounces=16, flags=bm.BM_FLAG_KSLOT), bm.FrameParams(W, H, spp=65536, max_bounces=3, flags=bm.BM_FLAG_KSLOT)):
+        with pytest.raises(Exception) as e:
+            scene256.render(cam, bad, acc)
+        assert "K-slot" in str(e.value)
+    ok = bm.FrameParams(W, H, spp=1, max_bounces=15, flags=bm.BM_FLAG_KSLOT)
+    acc_k = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    scene256.render(cam, ok, acc_k)
+    acc_d = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    scene256.render(cam, bm.FrameParams(W, H, spp=1, max_bounces=15), acc_d)
+    torch.cuda.synchronize()
+    assert torch.equal(acc_k.view(torch.int32), acc_d.view(torch.int32))
+    # 32-bit ticket counters: (chunk, sample) items of a 4K frame at 100 000 spp would wrap them
+    with pytest.raises(Exception) as e:
+        scene256.render(cam, bm.FrameParams(3840, 2160, spp=100000, max_bounces=3, flags=bm.BM_FLAG_SAMPLE_ITEMS), torch.zeros((2160, 3840, 4), dtype=torch.float32, device="cuda:0"))
+    assert "ticket" in str(e.value)
+
+
+def test_bench_starts_its_own_ranks(bm, torch_cuda, tmp_path):
+    """`python bench.py --gpus 2 ...` with NO launcher and no WORLD_SIZE in the environment (how the driver starts the N = 1 run, and
+    possibly the scaling runs): bench.py re-runs itself under torch.distributed.run, one rank per GPU, and rank 0's single JSON line
+    comes out of the parent's stdout -- with the per-rank clocks, the devices and the communicator's own rank count in it.
+    (Both ranks share this GPU: gloo group; the second run takes the C-ABI exchange over the stand-in transport.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from conftest import build_fake_rccl
+    fake = build_fake_rccl(tmp_path)
+    for capi in (False, True):
+        env = dict(os.environ, BM_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BM_BENCH_FORCE_DIST"):
+            env.pop(k, None)
+        if capi:
+            env.update(BM_DIST_CAPI="1", BM_RCCL_LIBRARY=fake)
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "config1", "--verify"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(line) == 1, r.stdout[-1500:]
+        out = json.loads(line[0])
+        assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0
+        assert out["verified_against_single_gpu"]["frames"] == 4 and out["verified_against_single_gpu"]["max_rel_err"] < 1e-5
+        ranks = out["ranks"]
+        assert ranks["process_group_world"] == 2 and len(ranks["ms_per_step"]) == 2 and len(ranks["devices"]) == 2 and all(t > 0 for t in ranks["ms_per_step"])
+        assert ranks["communicator_world"] == (2 if capi else None)
+        assert abs(max(ranks["ms_per_step"]) - out["ms_per_step"]) < 1e-3  # the line's time is the slowest rank's
+
+
 def test_frames_overlapping_on_two_streams(bm, orc, torch_cuda, scene256):
     """Consecutive frames issued on two streams (what bench.py --pipeline 2 does) may run at the same time: every launch has its
     own ticket counters and constants, and with BM_FLAG_SAMPLE_ITEMS samples are added atomically, so the buffer ends up

@@ -90,6 +90,9 @@ struct Params {
 	double cSpill = 120, cPull = 140;
 	double refillLat = 1.5; // load latencies a refill stalls its wave for (the atomic's round trip); 0 models tickets fetched ahead of time
 	double wB = 1.0, wC = 1.0; // policy 2: run the pass type with the largest (lanes * weight); the walk has weight 1
+	int offload = 0; // round 5: 1 = a shade pass hands a path's SHADOW ray to an idle lane of the wave (if there is one) and the owner goes straight on
+	                 // with its bounce ray (or ends): shadow and bounce rays walk side by side instead of one after the other.  K = 1 only.
+	double cOff = 30; // instructions the exchange adds to a shade pass in which at least one ray is handed over
 };
 
 struct Slot {
@@ -101,6 +104,7 @@ struct Slot {
 	int px, py, pz, sx, sy, sz, oct;
 	uint32_t cube = 0; bool nojump = false;
 	bool busy = false; // claimed by a wave: invisible to the scans of the others until that wave's next round
+	bool helper = false; // offload mode: this lane traces a shadow ray on behalf of another lane's path
 };
 
 struct World {
@@ -212,6 +216,7 @@ struct Sim {
 	bool final_launch = false; // the follow-up launch: takes pages, spills nothing
 	int waves_running = 0;
 	uint64_t spilled = 0, pulled = 0, late = 0, spill_events = 0;
+	uint64_t offloaded = 0;
 
 	// one scheduler round of a wave: applies the functional effects now, returns the issue / latency segments it costs
 	void round(Wave& w, double now) {
@@ -359,22 +364,37 @@ struct Sim {
 			return nullptr;
 		};
 		if (phase == 2) {
-			int n = 0;
+			int n = 0, handed = 0;
 			for (int l = 0; l < 64; ++l) {
 				Slot* s = pick(l, [](int st) { return st == S_NEED; });
 				if (!s) continue;
 				n++;
 				claim(s);
 				if (s->ray) rays_done++;
+				if (P.offload && K == 1 && s->next_ray < s->ray_end && g_rays[s->next_ray].kind == 1) {
+					// the next ray is a shadow ray: an idle lane of the wave takes it, the owner continues with what follows
+					Slot* idle = nullptr;
+					for (int l2 = 0; l2 < 64 && !idle; ++l2) if (slots[l2].st == S_IDLE && !slots[l2].busy) idle = &slots[l2];
+					if (idle) {
+						idle->next_ray = s->next_ray; idle->ray_end = s->next_ray + 1; idle->ray = &g_rays[idle->next_ray++];
+						idle->helper = true;
+						idle->st = setup(*idle, *idle->ray, P);
+						if (idle->st == S_IDLE) idle->st = S_NEED;
+						claim(idle);
+						s->next_ray++;
+						handed++; n++;
+					}
+				}
 				if (s->next_ray < s->ray_end) {
 					s->ray = &g_rays[s->next_ray++];
 					s->st = setup(*s, *s->ray, P);
 				} else {
-					s->st = S_IDLE; s->ray = nullptr; paths_done++;
+					s->st = S_IDLE; s->ray = nullptr; if (!s->helper) paths_done++; s->helper = false;
 				}
 			}
+			offloaded += handed;
 			st.runs[3]++; st.lanes[3] += n;
-			add(3, (P.split == 1 ? P.cGen + P.cRec : P.cC + (P.split == 2 ? 90 : 0)) + P.ovC, 1);
+			add(3, (P.split == 1 ? P.cGen + P.cRec : P.cC + (P.split == 2 ? 90 : 0)) + P.ovC + (handed ? P.cOff : 0), 1);
 		} else if (phase == 1) {
 			int n = 0, longest = 0;
 			for (int l = 0; l < 64; ++l) {
@@ -438,9 +458,9 @@ struct Sim {
 int main(int argc, char** argv) {
 	Params P;
 	std::map<std::string, double*> dk = {{"qB", &P.qB}, {"qC", &P.qC}, {"lat", &P.lat}, {"cpi", &P.cpi}, {"ovJ", &P.ovJ}, {"ovS", &P.ovS}, {"ovB", &P.ovB}, {"ovC", &P.ovC},
-										 {"sched", &P.schedMul}, {"cJ", &P.cJ}, {"cS", &P.cS}, {"cB", &P.cB}, {"cBstep", &P.cBstep}, {"cC", &P.cC}, {"cSched", &P.cSched}, {"cRefill", &P.cRefill}, {"wB", &P.wB}, {"wC", &P.wC}, {"beta", &P.beta}, {"cSpill", &P.cSpill}, {"cPull", &P.cPull}, {"refillLat", &P.refillLat}};
+										 {"sched", &P.schedMul}, {"cJ", &P.cJ}, {"cS", &P.cS}, {"cB", &P.cB}, {"cBstep", &P.cBstep}, {"cC", &P.cC}, {"cSched", &P.cSched}, {"cRefill", &P.cRefill}, {"wB", &P.wB}, {"wC", &P.wC}, {"beta", &P.beta}, {"cSpill", &P.cSpill}, {"cPull", &P.cPull}, {"refillLat", &P.refillLat}, {"cOff", &P.cOff}};
 	std::map<std::string, int*> ik = {{"K", &P.K}, {"W", &P.W}, {"refillmin", &P.refill_min}, {"tiles", &P.tiles}, {"policy", &P.policy}, {"jumpmin", &P.jump_min},
-									  {"jumppasses", &P.jump_passes}, {"steps", &P.steps_per_round}, {"rep", &P.rep}, {"pool", &P.pool}, {"minfill", &P.minfill}, {"split", &P.split}, {"twolaunch", &P.twolaunch}, {"spill", &P.spill}, {"spillkeep", &P.spill_keep}, {"splittiles", &P.split_tiles}};
+									  {"jumppasses", &P.jump_passes}, {"steps", &P.steps_per_round}, {"rep", &P.rep}, {"pool", &P.pool}, {"minfill", &P.minfill}, {"split", &P.split}, {"twolaunch", &P.twolaunch}, {"spill", &P.spill}, {"spillkeep", &P.spill_keep}, {"splittiles", &P.split_tiles}, {"offload", &P.offload}};
 	std::vector<std::string> sweeps;
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i];
@@ -578,6 +598,7 @@ int main(int argc, char** argv) {
 		}
 		printf("   brick loop %.1f cells;  sched+refill %.1fM instr;  total %.3fG wave instr, lanes/instr %.1f\n", S.brick_loop / std::max(1.0, S.brick_passes), S.instr[4] * scale / 1e6, total_instr * scale / 1e9,
 			   lane_instr / (total_instr - S.instr[4]));
+		if (P.offload) printf("   offload: %.3fM shadow rays handed to idle lanes\n", sim.offloaded * scale / 1e6);
 		if (P.spill) printf("   spill <= %d lanes (keep %d waves): %llu records in %llu spills, %llu taken in-kernel, %zu pages left to the follow-up launch (first launch ends at %.3f ms)\n", P.spill, P.spill_keep, (unsigned long long)sim.spilled, (unsigned long long)sim.spill_events, (unsigned long long)(sim.pulled - sim.late), left_pages, t_first / 2.4e6);
 		if (g_lookups) printf("   coarse level (min over 4x4x4 blocks): of %.1fM field lookups, block-min >= 2 / 4 / 8 / 16: %.1f %% / %.1f %% / %.1f %% / %.1f %%\n", g_lookups / 1e6,
 							  100.0 * g_coarse_hits[0] / g_lookups, 100.0 * g_coarse_hits[1] / g_lookups, 100.0 * g_coarse_hits[2] / g_lookups, 100.0 * g_coarse_hits[3] / g_lookups);
