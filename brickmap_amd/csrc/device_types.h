@@ -73,6 +73,8 @@ struct FrameConstants {
 	int tiles_x, tiles_y; // 16x16-pixel tiles covering this shard's rows
 	int xcd_handout;      // 1: XCD-aware hand-out (trace.hip refill: 256x256-pixel super-tiles dealt to the eight XCDs' counters); big frames only
 	int refill_min;       // a wave takes new work items once this many of its lanes are idle (frame_constants(): by the length of an item)
+	int helpers;          // 1: shadow rays may be traced by idle lanes of the wave and added with float atomics (trace.hip HELP); 0: every pixel's events
+	                      // are accumulated in path order by the one lane that owns it (BM_FLAG_ORDERED, and every frame that writes hit records)
 };
 
 struct DeviceCounters { // v: same order as bm_counters; sched: same order as bm_sched_stats

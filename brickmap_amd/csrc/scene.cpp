@@ -127,6 +127,11 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp,
 	if (xcd_override == 0 || xcd_override == 1) fc->xcd_handout = xcd_override;
 	static const int refill_override = [] { const char* e = std::getenv("BM_REFILL_MIN"); return e ? std::atoi(e) : 0; }(); // tuning runs
 	if (refill_override >= 1 && refill_override <= 64) fc->refill_min = refill_override;
+	// shadow rays on helper lanes (trace.hip HELP): on unless the caller wants ordered sums; render() turns it off for frames that
+	// write hit records.  BM_HELPERS=0 / 1 overrides (A/B runs, tests).
+	fc->helpers = (fp->flags & (BM_FLAG_ORDERED | BM_FLAG_PRIMARY_ONLY)) ? 0 : 1;
+	static const int help_override = [] { const char* e = std::getenv("BM_HELPERS"); return e ? std::atoi(e) : -1; }();
+	if (help_override == 0 || (help_override == 1 && !(fp->flags & BM_FLAG_PRIMARY_ONLY))) fc->helpers = help_override;
 	// The hand-out counts tickets in 32 bits (trace.hip: `my_tickets`, `base + want`).  The busiest counter owns a 1/8 share of the
 	// units -- groups of four chunks, or 256x256-pixel super-tiles of 4096 chunks -- times 16 tickets per chunk and, with (chunk,
 	// sample) items, per sample; every wave may overshoot a used-up counter once by up to 64.  Refuse what would wrap.
@@ -911,6 +916,7 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 	if (!accum) { set_error("null accumulation buffer"); return BM_EINVAL; }
 	FrameConstants fc;
 	if (int e = fill_frame_constants(cam, fp, &fc)) return e;
+	if (dbg) fc.helpers = 0; // hit records are per pixel, in path order: the owner traces every ray of its paths
 	BM_HIP(hipSetDevice(device_));
 	// `stream` is used as given: nullptr is HIP's default stream (what the reference's <<<>>> launches use), which is
 	// ordered with the caller's other default-stream work (e.g. torch's fill kernels on the accumulation buffer).

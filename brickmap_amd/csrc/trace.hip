@@ -34,7 +34,7 @@ namespace bm {
 //            whatever ray each of those lanes traces next                       (expensive, once per ray)
 // Scheduling changes only WHEN a lane's operations happen, never their operands, so results are
 // identical to the reference's per-ray functions run one ray at a time (the oracle).
-enum : int { P_GEN = 0, P_EXT_DONE = 1, P_SHD_DONE = 2, P_BOUNCE = 3 };
+enum : int { P_GEN = 0, P_EXT_DONE = 1, P_SHD_DONE = 2, P_BOUNCE = 3, P_HELPER = 6 };
 enum : int { ST_IDLE = 4, ST_CONN = 5 };
 
 #ifndef BM_WAVES_PER_SIMD
@@ -87,7 +87,15 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #endif
 // XCD: the XCD-aware hand-out (FrameConstants::xcd_handout; big frames) -- an instantiation of its own, so that the hand-out code of
 // the headline kernel stays what it was (as a run-time branch it cost config 2 0.5-1 %)
-template <bool DBG, bool XCD = false>
+// HELP: shadow rays on helper lanes (FrameConstants::helpers).  A path's shadow ray (connect, kernel.cu:328-346) and its next extend
+// ray are independent -- the reference itself traces them from two different queues -- but a lane that traces both does so one
+// after the other.  With HELP, a shade pass that finds idle lanes in its wave hands the shadow rays of the lanes it just shaded to
+// them (ten words through the LDS brick staging area, which no shade pass uses), the owner goes straight on with its bounce ray (or
+// ends the path), and the helper adds the unoccluded sun light to the pixel with float atomics, as the reference's connect does
+// (kernel.cu:341-343).  The rays traced are the same rays; what changes is who walks them: idle lanes do useful work without a
+// refill, and a path's latency -- which is what the end of a frame waits for -- is its extend rays' alone.  Pixels are therefore
+// written back with atomics as well (the accumulator starts at zero in the lane), so radiance is equal up to summation order.
+template <bool DBG, bool XCD = false, bool HELP = false>
 // (the instrumented variant carries hit records and counters: it gets the registers instead of the occupancy)
 __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, float4* __restrict__ accum,
 												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters,
@@ -107,6 +115,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	const bool sample_items = (fc.flags & 4u) != 0u; // BM_FLAG_SAMPLE_ITEMS
 	constexpr uint32_t kParts = 16u / BM_ITEM_LANES; // tickets per chunk and sample
 	const uint32_t items_per_chunk = (sample_items ? static_cast<uint32_t>(fc.spp > 0 ? fc.spp : 1) : 1u) * kParts;
+	const bool atomic_acc = HELP || sample_items; // other lanes may add to the pixel while this one holds it: add, never overwrite
 
 	// per-pixel state
 	uint32_t xy = 0;          // x | y << 16
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						s_end = sample_items ? s + 1 : fc.spp;
 						pstate = P_GEN;
 						state = ST_NEED;
-						acc = sample_items ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[local_pixel];
+						acc = atomic_acc ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[local_pixel];
 						if (DBG) {
 							d0 = 0; d1 = 0; d2 = 0xFFFFFFFFu; d3 = 0; hseg = 2166136261u; hsh = 2166136261u; next = 0; nsh = 0;
 							loads0 = tally.index_loads;
@@ -268,9 +277,10 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			// ================= phase C: shade the finished extend ray / generate the next primary ray, then set the new ray up
 			unsigned long long t_sub = t_phase;
 			(void)t_sub;
+			bool need_setup = false;
+			bool hand = false; // HELP: this lane has just drawn a shadow ray that an idle lane may take
+			f3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f);
 			if (state == ST_NEED || state == ST_CONN) {
-				bool need_setup = false;
-				f3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f);
 				if (state == ST_CONN) {
 					// ---- connect (kernel.cu:328-346) -- runs after shade within the same reference frame -- then the stored bounce
 					// ray is set up by the code below, together with the rays of the lanes that were shaded in this pass
@@ -284,17 +294,26 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 							hsh = hmix(hsh, static_cast<uint32_t>(info.sub_id) | (static_cast<uint32_t>(info.level) << 12));
 						}
 					}
-					if (!occluded) {
-						acc.x += scolor.x; acc.y += scolor.y; acc.z += scolor.z;
-					}
-					state = ST_NEED;
-					if (terminated) {
-						s++;
-						pstate = P_GEN; // the next primary ray (or the pixel hand-back) follows below
+					if (HELP && pstate == P_HELPER) {
+						// a helper's shadow ray: the sun light goes to the OWNER's pixel (kernel.cu:341-343: atomicAdd), the lane is free again
+						if (!occluded) {
+							float* a = reinterpret_cast<float*>(accum + local_pixel);
+							unsafeAtomicAdd(a + 0, scolor.x); unsafeAtomicAdd(a + 1, scolor.y); unsafeAtomicAdd(a + 2, scolor.z);
+						}
+						state = ST_IDLE; // (pstate stays P_HELPER: none of the blocks below applies)
 					} else {
-						bounces++;
-						pstate = P_BOUNCE; // neither shaded nor generated below: only set up
-						ro = hitp; rd = bdir; r.n = pn; shadow = false; need_setup = true;
+						if (!occluded) {
+							acc.x += scolor.x; acc.y += scolor.y; acc.z += scolor.z;
+						}
+						state = ST_NEED;
+						if (terminated) {
+							s++;
+							pstate = P_GEN; // the next primary ray (or the pixel hand-back) follows below
+						} else {
+							bounces++;
+							pstate = P_BOUNCE; // neither shaded nor generated below: only set up
+							ro = hitp; rd = bdir; r.n = pn; shadow = false; need_setup = true;
+						}
 					}
 				}
 				BM_MARK(0, t_sub); // connect
@@ -357,6 +376,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 							ro = hitp; rd = view;
 							shadow = true;
 							need_setup = true;
+							hand = HELP;
 						} else {
 							// ---- shade, miss branch (kernel.cu:316-323)
 							f3 c;
@@ -373,10 +393,45 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					}
 				}
 				BM_MARK(2, t_sub); // sky model (+ the tail of the shade block)
+			}
+			if (HELP) {
+				// ---- hand shadow rays to idle lanes: the k-th lane that has one writes (origin, direction, colour, pixel) to slot k of the
+				// wave's part of the LDS staging area, the k-th idle lane reads slot k and becomes its helper
+				const unsigned long long hand_m = __ballot(hand), free_m = __ballot(state == ST_IDLE);
+				if (hand_m != 0ull && free_m != 0ull) {
+					const int n_pairs = min(__popcll(hand_m), __popcll(free_m));
+					const int hrank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hand_m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hand_m), 0u));
+					const int frank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(free_m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(free_m), 0u));
+					float2* const slots = reinterpret_cast<float2*>(lds_brick) + (threadIdx.x & ~63u); // slot k, word pair j at [j * 256 + k]
+					const bool gives = hand && hrank < n_pairs, takes = state == ST_IDLE && frank < n_pairs;
+					if (gives) {
+						slots[0 * 256 + hrank] = make_float2(ro.x, ro.y);
+						slots[1 * 256 + hrank] = make_float2(ro.z, rd.x);
+						slots[2 * 256 + hrank] = make_float2(rd.y, rd.z);
+						slots[3 * 256 + hrank] = make_float2(scolor.x, scolor.y);
+						slots[4 * 256 + hrank] = make_float2(scolor.z, __uint_as_float(local_pixel));
+						// the owner is done with this shadow ray: what connect would have done next happens now
+						if (terminated) { s++; pstate = P_GEN; need_setup = false; }
+						else { bounces++; ro = hitp; rd = bdir; r.n = pn; shadow = false; }
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					if (takes) {
+						const float2 a = slots[0 * 256 + frank], b = slots[1 * 256 + frank], c = slots[2 * 256 + frank], d = slots[3 * 256 + frank], e = slots[4 * 256 + frank];
+						ro = mk(a.x, a.y, b.x); rd = mk(b.y, c.x, c.y); scolor = mk(d.x, d.y, e.x);
+						local_pixel = __float_as_uint(e.y);
+						shadow = true;
+						pstate = P_HELPER;
+						need_setup = true;
+					}
+				}
+			}
+			if (state == ST_NEED) {
 				if (pstate == P_GEN) {
 					if (s >= s_end) {
 						// item finished: write the accumulator back (or add this sample's share) and wait for the next one
-						if (sample_items) {
+						if (atomic_acc) {
 							float* a = reinterpret_cast<float*>(accum + local_pixel);
 							unsafeAtomicAdd(a + 0, acc.x); unsafeAtomicAdd(a + 1, acc.y); unsafeAtomicAdd(a + 2, acc.z); unsafeAtomicAdd(a + 3, acc.w);
 						} else {
@@ -413,14 +468,14 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					}
 				}
 				BM_MARK(3, t_sub); // pixel hand-back + primary ray
-				if (need_setup) {
-					if (shadow) r.n = mk(0.f, 0.f, 0.f); // connect passes a zeroed normal (kernel.cu:338)
-					pstate = shadow ? P_SHD_DONE : P_EXT_DONE;
-					const int st = ray_setup<DBG>(sc, ro, rd, r, tally);
-					state = (st == ST_NEED && shadow) ? ST_CONN : st;
-				}
-				BM_MARK(4, t_sub); // ray set-up
 			}
+			if (need_setup) {
+				if (shadow) r.n = mk(0.f, 0.f, 0.f); // connect passes a zeroed normal (kernel.cu:338)
+				pstate = shadow ? ((HELP && pstate == P_HELPER) ? P_HELPER : P_SHD_DONE) : P_EXT_DONE;
+				const int st = ray_setup<DBG>(sc, ro, rd, r, tally);
+				state = (st == ST_NEED && shadow) ? ST_CONN : st;
+			}
+			BM_MARK(4, t_sub); // ray set-up
 		} else if (phase == 1) {
 			if (BM_PRIO) __builtin_amdgcn_s_setprio(BM_PRIO_B);
 			if (BM_TIMED) { runsB++; lanesB += nB; }
@@ -596,13 +651,16 @@ void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameCo
 #else
 	DeviceCounters* const plain_counters = nullptr;
 #endif
+	const bool help = fc.helpers != 0;
+#define BM_LAUNCH_TRACE(D, X, H, DBGBUF, CNT) hipLaunchKernelGGL((trace_paths<D, X, H>), grid, block, 0, stream, sc, fc_dev, acc4, DBGBUF, CNT, work_counter)
 	if (instrumented) {
-		if (xcd) hipLaunchKernelGGL((trace_paths<true, true>), grid, block, 0, stream, sc, fc_dev, acc4, dbg, counters, work_counter);
-		else hipLaunchKernelGGL((trace_paths<true, false>), grid, block, 0, stream, sc, fc_dev, acc4, dbg, counters, work_counter);
+		if (xcd) { if (help) BM_LAUNCH_TRACE(true, true, true, dbg, counters); else BM_LAUNCH_TRACE(true, true, false, dbg, counters); }
+		else { if (help) BM_LAUNCH_TRACE(true, false, true, dbg, counters); else BM_LAUNCH_TRACE(true, false, false, dbg, counters); }
 	} else {
-		if (xcd) hipLaunchKernelGGL((trace_paths<false, true>), grid, block, 0, stream, sc, fc_dev, acc4, nullptr, plain_counters, work_counter);
-		else hipLaunchKernelGGL((trace_paths<false, false>), grid, block, 0, stream, sc, fc_dev, acc4, nullptr, plain_counters, work_counter);
+		if (xcd) { if (help) BM_LAUNCH_TRACE(false, true, true, nullptr, plain_counters); else BM_LAUNCH_TRACE(false, true, false, nullptr, plain_counters); }
+		else { if (help) BM_LAUNCH_TRACE(false, false, true, nullptr, plain_counters); else BM_LAUNCH_TRACE(false, false, false, nullptr, plain_counters); }
 	}
+#undef BM_LAUNCH_TRACE
 }
 
 void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const uint32_t* indices_queue, uint32_t* arena, uint32_t count,

@@ -51,6 +51,13 @@ extern "C" {
                                    same paths, same per-pixel event order, hit records bit-identical to the default schedule's
                                    (the environment variable BM_SCHEDULE=kslot selects it for every frame of the process) */
 
+#define BM_FLAG_ORDERED 16u     /* every pixel's events are accumulated in path order by the one lane that owns it and written back with
+                                   one plain store: a frame's sums are reproducible bit for bit.  WITHOUT this flag (the default) a wave
+                                   may hand a path's shadow ray to one of its idle lanes (csrc/trace.hip HELP): the same rays are
+                                   traced, the unoccluded sun light is added to the pixel with float atomics like the reference's
+                                   connect does (kernel.cu:341-343), and radiance is equal up to summation order (~1e-7 relative).
+                                   Frames that write hit records (debug_dev != NULL) and K-slot frames are always ordered. */
+
 typedef struct bm_scene bm_scene; /* Scene + its GPUScene view (Scene.h:7-44), one GPU */
 
 /* camera.h:3-10 -- only the fields the kernels read (launch_kernels:384-385,416). */
