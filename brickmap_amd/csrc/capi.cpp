@@ -130,6 +130,12 @@ int bm_host_generate_supercell(int grid_size, int grid_height, int sx, int sy, i
 	return 0;
 }
 
+int bm_debug_division_magic(uint32_t divisor, uint32_t* magic, int* shift) {
+	if (!magic || !shift || divisor < 3u || divisor >= (1u << 23)) { bm::set_error("bad argument"); return BM_EINVAL; }
+	bm::division_magic(divisor, magic, shift);
+	return 0;
+}
+
 int bm_host_cube_field(int grid_size, int grid_height, uint8_t* field, size_t capacity, size_t* bytes) {
 	bm::World w;
 	if (!w.dims.set(grid_size, grid_height)) { set_error("bad world dimensions"); return BM_EINVAL; }

@@ -23,13 +23,18 @@ struct DeviceScene {
 	uint32_t* index_grid;
 	const uint32_t* pool_base;
 	const uint32_t* brick_arena; // 16 words per brick
-	// octant cube field (traverse.h "cube-field walk"): 8 planes of one byte per cell of the grid plus a one-cell border,
-	// x-fastest; byte = edge of the largest empty cube with the cell as near corner along the plane's octant (bit 0 / 1 /
-	// 2 of the plane number = direction negative in x / y / z), 0 = the cell holds a brick, 255 = border (outside).
-	// Points 15 * (1 + cf_x + cf_xy) bytes BEFORE plane 0: the walk indexes it with the biased fields of the packed cell.
+	// octant cube field (traverse.h "cube-field walk"): 8 planes of one byte per cell of the grid plus a one-cell border;
+	// byte = edge of the largest empty cube with the cell as near corner along the plane's octant (bit 0 / 1 / 2 of the plane
+	// number = direction negative in x / y / z), 0 = the cell holds a brick, 255 = border (outside).  Rows (x) are padded to
+	// 2^cf_shift bytes, a slice is (cells + 2) rows: entry (x, y, z) of plane o is at
+	//     o * cf_plane + (z + 1) * cf_pxy + ((y + 1) << cf_shift) + (x + 1)
+	// and that offset is what a ray keeps as its current cell (traverse.h cell_offset).
 	const uint8_t* cube_field;
-	int cf_x, cf_xy;    // row / slice pitch in cells
-	uint32_t cf_plane;  // bytes per plane
+	int cf_shift;        // log2 of the row pitch
+	uint32_t cf_pxy;     // slice pitch in bytes: (cells + 2) << cf_shift
+	uint32_t cf_plane;   // bytes per plane: (cells_height + 2) * cf_pxy
+	uint32_t cf_magic;   // floor(n / cf_pxy) == umulhi(n, cf_magic) >> cf_magic_shift for every n < 2^30 (scene.cpp division_magic)
+	int cf_magic_shift;
 	int* load_queue;             // 3 ints per entry
 	uint32_t* load_queue_count;
 	uint32_t queue_cap;

@@ -41,8 +41,8 @@ __device__ __forceinline__ void unpack_walk(const DeviceScene& sc, const uint4& 
 	const uint32_t meta = c1.w;
 	r.cube = meta & kMetaCube;
 	r.sx = __builtin_amdgcn_sbfe(static_cast<int>(meta), kMetaSxShift, 2);
-	r.stepy = __builtin_amdgcn_sbfe(static_cast<int>(meta), kMetaSyShift, 2) << 11;
-	r.stepz = __builtin_amdgcn_sbfe(static_cast<int>(meta), kMetaSzShift, 2) << 22;
+	r.stepy = __builtin_amdgcn_sbfe(static_cast<int>(meta), kMetaSyShift, 2) << sc.cf_shift;
+	r.stepz = __mul24(__builtin_amdgcn_sbfe(static_cast<int>(meta), kMetaSzShift, 2), static_cast<int>(sc.cf_pxy));
 	r.field_off = ((meta >> kMetaOctShift) & 7u) * sc.cf_plane; // (a plane of the widest world has more than 2^24 bytes: no 24-bit multiply here)
 	r.last_axis = static_cast<int>((meta >> kMetaAxisShift) & 3u) - 1;
 }

@@ -493,6 +493,18 @@ void Scene::region_free_deferred(uint32_t bricks, uint32_t offset) {
 	pool_bricks_ -= bricks;
 }
 
+// floor(n / d) for every n < 2^30 as umulhi(n, magic) >> shift (Granlund-Montgomery: with l = ceil(log2 d) and
+// magic = ceil(2^(30 + l) / d) one has 2^(30+l) <= magic * d < 2^(30+l) + 2^l, which makes the truncated product exact for 30-bit n;
+// magic < 2^31 + 1 fits 32 bits; tests/test_host_logic.py replays it against integer division)
+void division_magic(uint32_t d, uint32_t* magic, int* shift) {
+	int l = 0;
+	while ((1ull << l) < d) ++l;
+	if (l < 2) l = 2;
+	const unsigned __int128 one = static_cast<unsigned __int128>(1) << (30 + l);
+	*magic = static_cast<uint32_t>((one + d - 1) / d);
+	*shift = l - 2; // (30 + l) - 32
+}
+
 // device half of Scene::generate (Scene.cpp:152-190): one flat index grid, one pool-base word per supercell and one
 // brick arena instead of 2 x supercells cudaMallocs and two pointer tables; plus the octant cube field of the walk.
 int Scene::allocate_device() {
@@ -511,17 +523,27 @@ int Scene::allocate_device() {
 	view_.pool_base = d_pool_base_;
 	view_.brick_arena = nullptr;
 	if (int e = arena_open(4 * run + 32ull * static_cast<uint64_t>(d.supercells) + (1ull << 16))) return e;
-	{ // octant cube field: what the walk reads instead of index words while it crosses empty space
+	{ // octant cube field: what the walk reads instead of index words while it crosses empty space.  Device layout: rows padded to a
+	  // power of two, so that a cell's entry offset -- which is what a ray carries as its position (traverse.h cell_offset) -- moves by
+	  // +-1 / +- 2^shift / +- slice pitch; the host builds the field with tight rows (world.cpp) and every slice is copied row by row.
 		std::vector<uint8_t> field;
 		world.build_cube_field(field, 8);
-		const int cfx = d.cells + 2;
-		BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cube_field_), field.size()));
-		BM_HIP(hipMemcpy(d_cube_field_, field.data(), field.size(), hipMemcpyHostToDevice));
-		view_.cf_x = cfx;
-		view_.cf_xy = cfx * cfx;
-		view_.cf_plane = static_cast<uint32_t>(field.size() / 8);
-		view_.cube_field = reinterpret_cast<const uint8_t*>(reinterpret_cast<uintptr_t>(d_cube_field_) - static_cast<uintptr_t>(15) * (1 + cfx + cfx * cfx));
-		cube_field_bytes_ = field.size();
+		const int X = d.cells + 2, Z = d.cells_height + 2;
+		int shift = 2;
+		while ((1 << shift) < X) ++shift;
+		const uint64_t pxy = static_cast<uint64_t>(X) << shift, plane = pxy * static_cast<uint64_t>(Z);
+		if (pxy >= (1ull << 23) || plane * 8 >= (1ull << 32)) { set_error("world too large for the 32-bit cube-field offsets of the walk"); return BM_EINVAL; }
+		BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cube_field_), plane * 8));
+		// 8 planes x Z slices, each X rows of X bytes -> rows of 2^shift bytes (the padding is never read)
+		for (int o = 0; o < 8; ++o)
+			BM_HIP(hipMemcpy2D(d_cube_field_ + static_cast<size_t>(o) * plane, static_cast<size_t>(1) << shift, field.data() + static_cast<size_t>(o) * X * X * Z, X, X,
+							   static_cast<size_t>(X) * Z, hipMemcpyHostToDevice));
+		view_.cf_shift = shift;
+		view_.cf_pxy = static_cast<uint32_t>(pxy);
+		view_.cf_plane = static_cast<uint32_t>(plane);
+		division_magic(view_.cf_pxy, &view_.cf_magic, &view_.cf_magic_shift);
+		view_.cube_field = d_cube_field_;
+		cube_field_bytes_ = plane * 8;
 	}
 	view_.cells = d.cells;
 	view_.cells_height = d.cells_height;

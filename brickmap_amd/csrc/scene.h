@@ -24,6 +24,8 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 		if (bm_e_ != hipSuccess) return ::bm::hip_fail(bm_e_, #expr, __FILE__, __LINE__); \
 	} while (0)
 
+void division_magic(uint32_t d, uint32_t* magic, int* shift); // floor(n / d) = umulhi(n, magic) >> shift for n < 2^30 (scene.cpp)
+
 class Scene {
 public:
 	explicit Scene(int device) : device_(device) {}

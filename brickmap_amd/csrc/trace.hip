@@ -80,6 +80,13 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #define BM_STEPS_PER_ROUND 4
 #endif
 // -DBM_PHASE_TIMING: profiling build in which the plain kernel also reports the scheduler statistics
+// -DBM_ISA_MARKERS: comment lines in the compiler's .s output at the boundaries of the scheduler's passes (tools/isa_passes.py
+// turns them into the per-pass instruction table of profiles/); a listing aid only -- the product is built without them
+#ifdef BM_ISA_MARKERS
+#define BM_REGION(name) asm volatile("; BM_REGION " name)
+#else
+#define BM_REGION(name) do { } while (0)
+#endif
 #ifdef BM_PHASE_TIMING
 #define BM_TIMED true
 #else
@@ -177,6 +184,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	unsigned long long t_dry = 0ull; // when this wave found the ticket counters empty (BM_TIMED): the rest of its life is the drain
 
 	for (;;) {
+		BM_REGION("refill");
 		// ---- refill: hand pixels to idle lanes, BM_ITEM_LANES at a time (consecutive tickets walk through a 4x4 chunk)
 		const unsigned long long idle = __ballot(state == ST_IDLE);
 		const int nI = __popcll(idle);
@@ -248,6 +256,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				}
 			}
 		}
+		BM_REGION("policy");
 		const int nJ = __popcll(__ballot(state == ST_JUMP));
 		const int nA = __popcll(__ballot(state == ST_OUTER)) + nJ; // lanes walking the brick grid, cell by cell or cube by cube
 		const int nB = __popcll(__ballot(state == ST_CAND));
@@ -277,6 +286,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			// ================= phase C: shade the finished extend ray / generate the next primary ray, then set the new ray up
 			unsigned long long t_sub = t_phase;
 			(void)t_sub;
+			BM_REGION("C.connect");
 			bool need_setup = false;
 			bool hand = false; // HELP: this lane has just drawn a shadow ray that an idle lane may take
 			f3 ro = mk(0.f, 0.f, 0.f), rd = mk(0.f, 0.f, 0.f);
@@ -317,6 +327,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					}
 				}
 				BM_MARK(0, t_sub); // connect
+				BM_REGION("C.shade");
 				if (pstate == P_EXT_DONE) {
 					// ---- extend finished (kernel.cu:226-238); `hit <=> distance < VERY_FAR`
 					const bool is_hit = r.hit;
@@ -369,6 +380,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						}
 					}
 					BM_MARK(1, t_sub); // shade, hit branch (cone sample, bounce direction)
+					BM_REGION("C.sky");
 					if (!is_hit || cast) {
 						const SkyView sv = sky_view(fc, view);
 						if (cast) {
@@ -394,6 +406,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				}
 				BM_MARK(2, t_sub); // sky model (+ the tail of the shade block)
 			}
+			BM_REGION("C.hand-over");
 			if (HELP) {
 				// ---- hand shadow rays to idle lanes: the k-th lane that has one writes (origin, direction, colour, pixel) to slot k of the
 				// wave's part of the LDS staging area, the k-th idle lane reads slot k and becomes its helper
@@ -427,6 +440,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					}
 				}
 			}
+			BM_REGION("C.generate");
 			if (state == ST_NEED) {
 				if (pstate == P_GEN) {
 					if (s >= s_end) {
@@ -469,6 +483,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				}
 				BM_MARK(3, t_sub); // pixel hand-back + primary ray
 			}
+			BM_REGION("C.set-up");
 			if (need_setup) {
 				if (shadow) r.n = mk(0.f, 0.f, 0.f); // connect passes a zeroed normal (kernel.cu:338)
 				pstate = shadow ? ((HELP && pstate == P_HELPER) ? P_HELPER : P_SHD_DONE) : P_EXT_DONE;
@@ -477,6 +492,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			}
 			BM_MARK(4, t_sub); // ray set-up
 		} else if (phase == 1) {
+			BM_REGION("B.candidate");
 			if (BM_PRIO) __builtin_amdgcn_s_setprio(BM_PRIO_B);
 			if (BM_TIMED) { runsB++; lanesB += nB; }
 			// ================= phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask DDA, streaming request)
@@ -506,6 +522,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			// cell); otherwise the lanes near the surface make a few single moves and the jumpers wait for company.
 			if (BM_PRIO) __builtin_amdgcn_s_setprio(BM_PRIO_A);
 			const int nO = nA - nJ;
+			BM_REGION("A.jump");
 			if (nJ * BM_JUMP_RATIO >= nO) {
 				int walkers = nA;
 #pragma unroll 1
@@ -524,6 +541,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					}
 				}
 			} else {
+				BM_REGION("A.single");
 #pragma unroll 1
 				for (int k = 0; k < BM_STEPS_PER_ROUND; ++k) {
 					if (BM_TIMED) { runsA++; lanesA += __popcll(__ballot(state == ST_OUTER)); }
@@ -534,6 +552,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				}
 			}
 		}
+		BM_REGION("loop-end");
 		if (BM_TIMED) {
 			const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_phase;
 			if (phase == 0) cycA += dt; else if (phase == 1) cycB += dt; else cycC += dt;

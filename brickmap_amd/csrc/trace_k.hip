@@ -342,8 +342,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_K_WAVES) void trace_paths_k(const
 					new_bit = 1u << st;
 					if (DBG && !n_representable(r.n)) tally.paths += 1u << 20; // (cannot happen: the packed normal would lose it -- poisons the path counter the tests compare)
 					const uint32_t oct = (rd.x < 0.f ? 1u : 0u) | (rd.y < 0.f ? 2u : 0u) | (rd.z < 0.f ? 4u : 0u);
-					const uint32_t meta = (r.cube & kMetaCube) | ((static_cast<uint32_t>(r.sx) & 3u) << kMetaSxShift) | ((static_cast<uint32_t>(r.stepy >> 11) & 3u) << kMetaSyShift) |
-										  ((static_cast<uint32_t>(r.stepz >> 22) & 3u) << kMetaSzShift) | (oct << kMetaOctShift) | (pack_n(r.n) << kMetaNShift) |
+					const uint32_t meta = (r.cube & kMetaCube) | ((static_cast<uint32_t>(r.sx) & 3u) << kMetaSxShift) | ((static_cast<uint32_t>(step_sign(r.stepy)) & 3u) << kMetaSyShift) |
+										  ((static_cast<uint32_t>(step_sign(r.stepz)) & 3u) << kMetaSzShift) | (oct << kMetaOctShift) | (pack_n(r.n) << kMetaNShift) |
 										  (shadow ? kMetaShadow : 0u);
 					lds[sb] = make_uint4(__float_as_uint(r.tx), __float_as_uint(r.ty), __float_as_uint(r.tz), r.p);
 					lds[sb + 256u] = make_uint4(__float_as_uint(r.dx), __float_as_uint(r.dy), __float_as_uint(r.dz), meta);

@@ -172,11 +172,12 @@ struct RayState {
 	f3 o, d;            // origin (brick units once set up) and direction
 	float tx, ty, tz;   // tmax
 	float dx, dy, dz;   // tdelta = |1/d|
-	uint32_t p;         // current brick cell, packed: (x + 16) | (y + 16) << 11 | (z + 16) << 22 (see pack_cell)
-	int sx, stepy, stepz; // packed-cell increment of a move along x / y / z: sign(d) << 0 / 11 / 22 (sy = stepy >> 11, ...)
+	uint32_t p;         // current brick cell AS THE BYTE OFFSET OF ITS CUBE-FIELD ENTRY (octant plane included, see cell_offset): the
+	                    // walk's lookup is a load at this offset, no address arithmetic; coordinates are recovered at candidates only
+	int sx, stepy, stepz; // increment of that offset for a move along x / y / z: sign(d) * (1, row pitch, slice pitch)
 	float tminn;
 	f3 n;               // normal carried in/out of the traversal (voxel.cuh:135 `normal`)
-	int last_step;      // packed-cell increment of the last move (0 before the first): which axis it was, see move_axis
+	int last_step;      // offset increment of the last move (0 before the first): which axis it was, see move_axis
 	int last_axis;      // the same as an axis number (-1 before the first move): what trace_k.hip keeps instead of last_step
 	uint32_t field_off;      // byte offset of the ray's octant plane in DeviceScene::cube_field
 	uint32_t cube;           // edge of the empty cube ahead of the current cell (its cube_field byte)
@@ -186,23 +187,32 @@ struct RayState {
 
 enum : int { ST_NEED = 0, ST_OUTER = 1, ST_CAND = 2, ST_JUMP = 3 };
 
-// Packed brick cell.  The three coordinates share one register, biased by one supercell (16) so that the cell just
-// outside the grid on the negative side is representable (15) and a move never borrows across fields: a move is ONE
-// add of a per-axis constant.  x, y: 11 bits (grids up to 1024 bricks wide), z: 10 bits (up to 992 high); Scene::init checks.
-constexpr uint32_t kCellBias = 16u;
-__device__ __forceinline__ uint32_t pack_cell(int x, int y, int z) {
-	return (static_cast<uint32_t>(x) + kCellBias) | ((static_cast<uint32_t>(y) + kCellBias) << 11) | ((static_cast<uint32_t>(z) + kCellBias) << 22);
+// The current cell is kept as the byte offset of its entry in the ray's octant plane of the cube field (DeviceScene::cube_field):
+//     offset = octant * cf_plane + ((z + 1) * (cells + 2) + (y + 1)) * 2^cf_shift + (x + 1)
+// (bordered coordinates: one border cell on every side, rows padded to a power of two).  A move is ONE add of a per-axis constant,
+// a jump three multiply-adds, and the byte the walk needs next is at cube_field[offset]: round 4 kept the three coordinates in
+// bit fields and spent seven vector instructions per lookup turning them into this offset (and / bfe / shift / two 24-bit
+// multiplies / adds), 1.8 M + 1.0 M times per 1080p frame.  The coordinates come back out where they are needed -- at candidates,
+// 0.4 M per frame: index word address, LoD distance, request -- with one exact multiply-high division by the slice pitch.
+__device__ __forceinline__ uint32_t cell_offset(const DeviceScene& sc, uint32_t field_off, int x, int y, int z) {
+	return field_off + __umul24(static_cast<uint32_t>(z + 1), sc.cf_pxy) + (static_cast<uint32_t>(y + 1) << sc.cf_shift) + static_cast<uint32_t>(x + 1);
 }
-__device__ __forceinline__ int cell_x(uint32_t p) { return static_cast<int>(p & 0x7FFu) - 16; }
-__device__ __forceinline__ int cell_y(uint32_t p) { return static_cast<int>((p >> 11) & 0x7FFu) - 16; }
-__device__ __forceinline__ int cell_z(uint32_t p) { return static_cast<int>(p >> 22) - 16; }
+__device__ __forceinline__ void cell_coords(const DeviceScene& sc, const RayState& r, int& x, int& y, int& z) {
+	const uint32_t rel = r.p - r.field_off;                               // < cf_plane < 2^30
+	const uint32_t fz = __umulhi(rel, sc.cf_magic) >> sc.cf_magic_shift;  // floor(rel / cf_pxy), exact (scene.cpp division_magic)
+	const uint32_t low = rel - __umul24(fz, sc.cf_pxy);
+	x = static_cast<int>(low & ((1u << sc.cf_shift) - 1u)) - 1;
+	y = static_cast<int>(low >> sc.cf_shift) - 1;
+	z = static_cast<int>(fz) - 1;
+}
+__device__ __forceinline__ int step_sign(int step) { return (step > 0) - (step < 0); }
 
-// axis of the last move from its packed increment: +-1 = x, +-2^11 = y, +-2^22 = z, 0 = no move yet (-1).  (A zero
+// axis of the last move from its offset increment: +-1 = x, +- row pitch = y, +- slice pitch = z, 0 = no move yet (-1).  (A zero
 // increment can only be selected for a direction with a zero component whose tmax of 1e6 is the smallest of the three:
 // impossible for a unit direction inside the grid.)
-__device__ __forceinline__ int move_axis(int last_step) {
+__device__ __forceinline__ int move_axis(const DeviceScene& sc, int last_step) {
 	const uint32_t a = static_cast<uint32_t>(last_step < 0 ? -last_step : last_step);
-	return a == 0u ? -1 : (a == 1u ? 0 : (a == (1u << 11) ? 1 : 2));
+	return a == 0u ? -1 : (a == 1u ? 0 : (a == (1u << sc.cf_shift) ? 1 : 2));
 }
 
 // ---- cube-field walk.  DeviceScene::cube_field holds, per direction octant and brick cell, the edge n of the largest
@@ -218,9 +228,7 @@ constexpr uint32_t kCubeNoJump = 0x100u; // RayState::cube flag: tmax is outside
 // The lookup in three pieces -- where the cell's byte lives, whether a jump may start from the current tmax, what the byte means
 // -- so that a kernel can issue the load in one pass and use the byte in a later one (trace_k.hip); field_lookup is their sum.
 __device__ __forceinline__ uint32_t field_index(const DeviceScene& sc, const RayState& r) {
-	const uint32_t fx = r.p & 0x7FFu, fy = (r.p >> 11) & 0x7FFu, fz = r.p >> 22;
-	// bordered cell coordinate = field - 15 (16-cell bias, one border cell): the three "- 15" are folded into sc.cube_field
-	return __umul24(fz, static_cast<uint32_t>(sc.cf_xy)) + (__umul24(fy, static_cast<uint32_t>(sc.cf_x)) + fx) + r.field_off;
+	return r.p; // the cell IS its entry's offset (cell_offset)
 }
 __device__ __forceinline__ bool field_jump_possible(const RayState& r) { // jump_possible(): tmax in the range jump.h handles
 	const float m = fminf(fminf(r.tx, r.ty), r.tz);
@@ -283,7 +291,7 @@ __device__ __forceinline__ uint32_t jump_advance(RayState& r) {
 	const float iz = DIR ? fabsf(r.d.z) : (dz > 0.f ? __builtin_amdgcn_rcpf(dz) : 0.f);
 	dda_jump(tx, ty, tz, dx, dy, dz, ix, iy, iz, n, cx, cy, cz, axis);
 	r.tx = tx; r.ty = ty; r.tz = tz;
-	// all three products fit 24-bit signed multiplies: counts <= 255, increments +-1 / +-2^11 / +-2^22
+	// all three products fit 24-bit signed multiplies: counts <= 255, increments +-1 / +- row pitch / +- slice pitch (< 2^23, Scene::init checks)
 	r.p += static_cast<uint32_t>(__mul24(static_cast<int>(cx), step_x) + __mul24(static_cast<int>(cy), step_y) + __mul24(static_cast<int>(cz), step_z));
 	r.last_step = axis == 0 ? step_x : (axis == 1 ? step_y : step_z); // (only read after a cube exit, where it is the exit axis)
 	r.last_axis = axis;
@@ -381,12 +389,15 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 	const int px = static_cast<int>(origin.x), py = static_cast<int>(origin.y), pz = static_cast<int>(origin.z);
 	const int cells = sc.cells, cells_h = sc.cells_height;
 	if (px < 0 || px >= cells || py < 0 || py >= cells || pz < 0 || pz >= cells_h) return ST_NEED;
-	r.p = pack_cell(px, py, pz);
+	// octant of the direction: a zero component never moves, either plane is valid for it
+	const uint32_t oct = (dir.x < 0.f ? 1u : 0u) | (dir.y < 0.f ? 2u : 0u) | (dir.z < 0.f ? 4u : 0u);
+	r.field_off = oct * sc.cf_plane;
+	r.p = cell_offset(sc, r.field_off, px, py, pz);
 	const float cbx = dir.x > 0.f ? static_cast<float>(px + 1) : static_cast<float>(px);
 	const float cby = dir.y > 0.f ? static_cast<float>(py + 1) : static_cast<float>(py);
 	const float cbz = dir.z > 0.f ? static_cast<float>(pz + 1) : static_cast<float>(pz);
 	const int sx = isign(dir.x), sy = isign(dir.y), sz = isign(dir.z);
-	r.sx = sx; r.stepy = sy * (1 << 11); r.stepz = sz * (1 << 22);
+	r.sx = sx; r.stepy = sy << sc.cf_shift; r.stepz = __mul24(sz, static_cast<int>(sc.cf_pxy));
 	const float rx = dir.x == 0.0f ? 0.0f : 1.f / dir.x;
 	const float ry = dir.y == 0.0f ? 0.0f : 1.f / dir.y;
 	const float rz = dir.z == 0.0f ? 0.0f : 1.f / dir.z;
@@ -397,9 +408,6 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 	r.last_step = 0;
 	r.last_axis = -1;
 	if (DBG) tally.index_loads++; // one per visited cell = the reference's index loads (algorithmic count)
-	// octant of the direction: a zero component never moves, either plane is valid for it
-	const uint32_t oct = (dir.x < 0.f ? 1u : 0u) | (dir.y < 0.f ? 2u : 0u) | (dir.z < 0.f ? 4u : 0u);
-	r.field_off = oct * sc.cf_plane;
 	return field_lookup(sc, r); // inside the grid: never a border cell
 }
 
@@ -409,8 +417,9 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 template <bool DBG, bool AXIS = false, bool OVERLAY = false>
 __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const int* campos, RayState& r, HitInfo& info, Tally& tally,
 													 unsigned long long* lds_brick, uint32_t* walk_trips = nullptr) {
-	const int px = cell_x(r.p), py = cell_y(r.p), pz = cell_z(r.p);
-	const int sx = r.sx, sy = r.stepy >> 11, sz = r.stepz >> 22; // step signs back from the packed increments
+	int px, py, pz;
+	cell_coords(sc, r, px, py, pz);
+	const int sx = r.sx, sy = step_sign(r.stepy), sz = step_sign(r.stepz); // step signs back from the offset increments
 	// inside the grid 0 <= pos < cells, so >>4 and &15 equal the reference's signed /16 and %16
 	// (24-bit multiplies: all operands are far below 2^24; a 32-bit v_mul_lo_u32 issues at a quarter of the rate)
 	const uint32_t sci = static_cast<uint32_t>((px >> 4) + __mul24(py >> 4, sc.sg_xy) + __mul24(pz >> 4, sc.sg_xy2));
@@ -424,7 +433,7 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	brick.q0 = brick.q1 = brick.q2 = brick.q3 = make_uint4(0u, 0u, 0u, 0u);
 	// voxel.cuh:202-206, by select: entry normal and entry distance from the axis of the last move; a ray that starts
 	// inside this cell (no move yet) keeps its normal and enters at distance 0
-	const int axis = AXIS ? r.last_axis : move_axis(r.last_step);
+	const int axis = AXIS ? r.last_axis : move_axis(sc, r.last_step);
 	const float new_distance = axis == 0 ? r.tx - r.dx : (axis == 1 ? r.ty - r.dy : (axis == 2 ? r.tz - r.dz : 0.f));
 	r.n = mk(axis == -1 ? r.n.x : (axis == 0 ? -static_cast<float>(sx) : 0.f), axis == -1 ? r.n.y : (axis == 1 ? -static_cast<float>(sy) : 0.f),
 			 axis == -1 ? r.n.z : (axis == 2 ? -static_cast<float>(sz) : 0.f));

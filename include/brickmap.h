@@ -178,6 +178,9 @@ BM_API int bm_host_column_heights(int grid_size, int grid_height, int sx, int sy
 BM_API int bm_host_generate_supercell(int grid_size, int grid_height, int sx, int sy, int sz, uint32_t* indices4096,
                                       uint32_t* brick_count, uint32_t* bricks, uint32_t brick_capacity);
 
+/* test door: the constants with which the walk divides a cube-field offset by the slice pitch (floor(n / divisor) ==
+ * (uint64(n) * magic >> 32) >> shift for every n < 2^30; 3 <= divisor < 2^23) */
+BM_API int bm_debug_division_magic(uint32_t divisor, uint32_t* magic, int* shift);
 /* The octant cube field the GPU walk reads instead of index words while it crosses empty space (no reference
  * counterpart: the reference loads one index word per visited cell, voxel.cuh:192-200).  8 planes of
  * (cells+2)^2 x (cells_height+2) bytes, x fastest, one border cell all round; plane o (bit 0 / 1 / 2 = direction

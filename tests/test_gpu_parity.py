@@ -129,7 +129,7 @@ def test_world_on_device_matches_oracle(bm, orc, torch_cuda, scene256, world256)
     info = scene256.info()
     assert info["total_bricks"] == world256.total_bricks() and info["resident_bricks"] == info["total_bricks"]
     assert info["index_bytes"] == world256.nsc * 16384 and info["pool_bytes"] == 64 * info["total_bricks"] <= info["brick_bytes"]
-    assert info["cube_field_bytes"] == 8 * 34 ** 3
+    assert info["cube_field_bytes"] == 8 * 34 * 34 * 64  # 8 planes x (cells_h + 2) slices x (cells + 2) rows, rows padded to a power of two
     for sc in range(world256.nsc):
         idx, bricks = scene256.host_supercell(sc)  # host side: the reference's words and brick order
         want_idx, want_bricks = world256.sc_indices(sc), world256.sc_bricks(sc)

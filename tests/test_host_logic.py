@@ -228,3 +228,25 @@ def test_bench_self_launch_command(monkeypatch):
     except Exception:
         pass  # (no GPU here: anything after the launch decision may fail)
     assert not seen
+
+
+def test_division_magic_is_exact():
+    """The walk keeps a ray's cell as the byte offset of its cube-field entry and divides it by the slice pitch at candidates with one
+    multiply-high (traverse.h cell_coords): floor(n / d) == (n * magic >> 32) >> shift must hold for EVERY offset n < 2^30.  Checked
+    for the slice pitches of the BASELINE worlds and awkward divisors: all multiples of d and their neighbours (where a rounded-down
+    reciprocal fails first), plus random offsets."""
+    import ctypes as C
+    from brickmap_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(5)
+    for d in [(18 << 5), (34 << 6), (130 << 8), (258 << 9), (514 << 10), (50 << 6), 3, 5, 7, 641, 65537, (1 << 20), (1 << 23) - 1, 1000003]:
+        magic, shift = C.c_uint32(0), C.c_int(0)
+        assert L.bm_debug_division_magic(d, C.byref(magic), C.byref(shift)) == 0
+        k = np.arange(0, (1 << 30) // d + 1, dtype=np.uint64)
+        if len(k) > 2_000_000:
+            k = np.unique(np.concatenate([k[:500_000], k[-500_000:], rng.integers(0, len(k), 1_000_000).astype(np.uint64)]))
+        n = np.concatenate([k * d, k * d + 1, (k + 1) * d - 1, rng.integers(0, 1 << 30, 1_000_000).astype(np.uint64)])
+        n = n[n < (1 << 30)]
+        got = ((n * np.uint64(magic.value)) >> np.uint64(32)) >> np.uint64(shift.value)
+        assert np.array_equal(got, n // np.uint64(d)), d
+    assert L.bm_debug_division_magic(2, C.byref(magic), C.byref(shift)) != 0

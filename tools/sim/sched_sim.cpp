@@ -92,6 +92,7 @@ struct Params {
 	double wB = 1.0, wC = 1.0; // policy 2: run the pass type with the largest (lanes * weight); the walk has weight 1
 	int offload = 0; // round 5: 1 = a shade pass hands a path's SHADOW ray to an idle lane of the wave (if there is one) and the owner goes straight on
 	                 // with its bounce ray (or ends): shadow and bounce rays walk side by side instead of one after the other.  K = 1 only.
+	int reserve = 0;  // offload: a refill leaves this many idle lanes unfilled (kept for shadow rays)
 	double cOff = 30; // instructions the exchange adds to a shade pass in which at least one ray is handed over
 };
 
@@ -242,7 +243,7 @@ struct Sim {
 		double sched_instr = P.cSched * P.schedMul;
 		if (w.work_left && nI >= P.refill_min) {
 			if (P.pool && nI > 64) nI = 64; // one idle slot per column and refill
-			const int want = nI / 4;
+			const int want = std::max(1, (nI - P.reserve) / 4);
 			const uint32_t total_groups = (total_chunks + 3u) >> 2;
 			const uint32_t my_groups = total_groups > (uint32_t)w.my_counter ? (total_groups - w.my_counter + 7u) / 8u : 0u;
 			const uint32_t my_tickets1 = my_groups * 4u * 4u;
@@ -460,7 +461,7 @@ int main(int argc, char** argv) {
 	std::map<std::string, double*> dk = {{"qB", &P.qB}, {"qC", &P.qC}, {"lat", &P.lat}, {"cpi", &P.cpi}, {"ovJ", &P.ovJ}, {"ovS", &P.ovS}, {"ovB", &P.ovB}, {"ovC", &P.ovC},
 										 {"sched", &P.schedMul}, {"cJ", &P.cJ}, {"cS", &P.cS}, {"cB", &P.cB}, {"cBstep", &P.cBstep}, {"cC", &P.cC}, {"cSched", &P.cSched}, {"cRefill", &P.cRefill}, {"wB", &P.wB}, {"wC", &P.wC}, {"beta", &P.beta}, {"cSpill", &P.cSpill}, {"cPull", &P.cPull}, {"refillLat", &P.refillLat}, {"cOff", &P.cOff}};
 	std::map<std::string, int*> ik = {{"K", &P.K}, {"W", &P.W}, {"refillmin", &P.refill_min}, {"tiles", &P.tiles}, {"policy", &P.policy}, {"jumpmin", &P.jump_min},
-									  {"jumppasses", &P.jump_passes}, {"steps", &P.steps_per_round}, {"rep", &P.rep}, {"pool", &P.pool}, {"minfill", &P.minfill}, {"split", &P.split}, {"twolaunch", &P.twolaunch}, {"spill", &P.spill}, {"spillkeep", &P.spill_keep}, {"splittiles", &P.split_tiles}, {"offload", &P.offload}};
+									  {"jumppasses", &P.jump_passes}, {"steps", &P.steps_per_round}, {"rep", &P.rep}, {"pool", &P.pool}, {"minfill", &P.minfill}, {"split", &P.split}, {"twolaunch", &P.twolaunch}, {"spill", &P.spill}, {"spillkeep", &P.spill_keep}, {"splittiles", &P.split_tiles}, {"offload", &P.offload}, {"reserve", &P.reserve}};
 	std::vector<std::string> sweeps;
 	for (int i = 1; i < argc; ++i) {
 		std::string a = argv[i];
