@@ -30,30 +30,71 @@ def assert_radiance(got, want):
 
 
 def gpu_render(bm, torch, scene, cam, params, accum=None, want_dbg=True, also_plain=True):
-    """Render through the C-ABI.  With want_dbg the instrumented instantiation trace_paths<true> runs (hit records for the
-    oracle comparison); the SAME frame is then rendered again with the production instantiation trace_paths<false> (the
-    one bench.py times: no hit records, no counters, twice the occupancy) and must give a bit-identical accumulator --
-    so every case that checks the instrumented kernel against the oracle also pins the benchmarked one.
-    The frame is rendered twice more with the K-slot schedule (BM_FLAG_KSLOT, csrc/trace_k.hip: instrumented and production
-    instantiation): same accumulator bits, same hit records -- every parity case pins both schedules."""
+    """Render through the C-ABI; returns the frame with ORDERED sums (BM_FLAG_ORDERED: reproducible bit for bit) and its hit records.
+    With want_dbg the instrumented instantiation trace_paths<true> runs (hit records for the oracle comparison); the SAME frame is
+    then rendered again
+      (a) with the production instantiation trace_paths<false> (no hit records, no counters, twice the occupancy), ordered: a
+          bit-identical accumulator;
+      (b) as production frames run by default -- shadow rays on helper lanes, added with float atomics (trace_paths<false, *, true>,
+          the kernel bench.py times): identical terminated-path counts, radiance equal up to summation order (2e-5);
+      (c) where the caller checks traversal counters (BM_FLAG_COUNTERS on a resident scene with clean counters): with helper lanes AND
+          counters, instrumented, no hit records -- the counters must equal the ordered frame's, i.e. the helpers walked the same rays;
+      (d) twice more with the K-slot schedule (BM_FLAG_KSLOT, csrc/trace_k.hip: instrumented and production instantiation): same
+          accumulator bits, same hit records.
+    So every case that checks the instrumented kernel against the oracle also pins the benchmarked one and both schedules."""
     import copy
     rows = bm.local_rows(params)
     if accum is None:
         accum = torch.zeros((rows, params.width, 4), dtype=torch.float32, device="cuda:0")
     check_kslot = os.environ.get("BM_TEST_KSLOT", "1") != "0" and not (params.flags & bm.BM_FLAG_KSLOT)
-    before = accum.clone() if ((want_dbg and also_plain) or check_kslot) else None
+    before = accum.clone() if (also_plain or check_kslot) else None
     dbg = torch.zeros((rows, params.width, 8), dtype=torch.int32, device="cuda:0") if want_dbg else None
-    scene.render(cam, params, accum, debug=dbg)
+    helper_counts = helper_acc = None
+    if want_dbg and (params.flags & bm.BM_FLAG_COUNTERS) and not (params.flags & (bm.BM_FLAG_ORDERED | bm.BM_FLAG_KSLOT)):
+        # the caller compares the scene's counters with the oracle's after this call: render the frame once with helper lanes AND
+        # counters first (instrumented instantiation, no hit records), keep its counts, and hand the caller a clean slate.  Only when
+        # the counters are clean and the scene is fully resident (an extra frame of a streaming scene changes what is requested).
+        info = scene.info()
+        if not any(scene.counters().values()) and info["resident_bricks"] == info["total_bricks"]:
+            scratch = accum.clone()
+            scene.render(cam, params, scratch)
+            torch.cuda.synchronize()
+            helper_counts, helper_acc = scene.counters(), scratch.cpu().numpy()
+            scene.counters_reset()
+    ordered = copy.copy(params)
+    ordered.flags = params.flags | bm.BM_FLAG_ORDERED  # the frame the caller gets: reproducible sums, whichever instantiation renders it
+    scene.render(cam, ordered, accum, debug=dbg)
     torch.cuda.synchronize()
     a = accum.cpu().numpy()
-    if want_dbg and also_plain:
-        plain = copy.copy(params)
-        plain.flags = params.flags & ~bm.BM_FLAG_COUNTERS
-        acc2 = before.clone()
-        scene.render(cam, plain, acc2)
-        torch.cuda.synchronize()
-        b = acc2.cpu().numpy()
-        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "trace_paths<false> differs from trace_paths<true>"
+    if also_plain:
+        # (a) ordered sums (BM_FLAG_ORDERED: one lane accumulates a pixel's events in path order): the same bits as the instrumented kernel
+        if want_dbg:
+            plain = copy.copy(params)
+            plain.flags = (params.flags & ~bm.BM_FLAG_COUNTERS) | bm.BM_FLAG_ORDERED
+            acc2 = before.clone()
+            scene.render(cam, plain, acc2)
+            torch.cuda.synchronize()
+            b = acc2.cpu().numpy()
+            if params.flags & bm.BM_FLAG_SAMPLE_ITEMS:
+                np.testing.assert_allclose(b, a, rtol=2e-5, atol=1e-7, err_msg="trace_paths<false> differs from trace_paths<true>")
+            else:
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "trace_paths<false> differs from trace_paths<true>"
+        # (b) the DEFAULT of production frames -- shadow rays on helper lanes, added with float atomics (trace.hip HELP) -- traces the same
+        # rays: terminated-path counts identical, radiance equal up to summation order
+        if not (params.flags & bm.BM_FLAG_ORDERED):
+            hp = copy.copy(params)
+            hp.flags = params.flags & ~(bm.BM_FLAG_COUNTERS | bm.BM_FLAG_ORDERED)
+            acc3 = before.clone()
+            scene.render(cam, hp, acc3)
+            torch.cuda.synchronize()
+            h = acc3.cpu().numpy()
+            assert np.array_equal(h[..., 3], a[..., 3]), "helper lanes: terminated-path counts differ"
+            np.testing.assert_allclose(h[..., :3], a[..., :3], rtol=2e-5, atol=1e-7, err_msg="helper lanes: radiance differs")
+    if helper_counts is not None:
+        # (c) the instrumented kernel WITH helper lanes (counters on, no hit records) walked exactly what this frame walked
+        assert scene.counters() == helper_counts, "helper lanes: traversal counters differ from the ordered frame's"
+        assert np.array_equal(helper_acc[..., 3], a[..., 3])
+        np.testing.assert_allclose(helper_acc[..., :3], a[..., :3], rtol=2e-5, atol=1e-7, err_msg="helper lanes (instrumented): radiance differs")
     if check_kslot:
         atomic_sum = bool(params.flags & bm.BM_FLAG_SAMPLE_ITEMS)  # samples of a pixel are added with float atomics: order not fixed
         # (without BM_FLAG_COUNTERS: the scene's traversal counters belong to the caller's own frames; test_kslot_counters pins the K-slot ones)
@@ -388,7 +429,7 @@ def test_sharded_equals_unsharded_and_accumulation(bm, orc, torch_cuda, scene256
     # two launches of 1 spp == one launch of 2 spp (same per-pixel accumulation order)
     acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
     for s in range(2):
-        scene256.render(cam, bm.FrameParams(W, H, spp=1, sample_base=s, max_bounces=3), acc)
+        scene256.render(cam, bm.FrameParams(W, H, spp=1, sample_base=s, max_bounces=3, flags=bm.BM_FLAG_ORDERED), acc)
     torch.cuda.synchronize()
     assert np.array_equal(acc.cpu().numpy(), full)
 
@@ -1077,7 +1118,7 @@ def test_long_paths_and_schedule_limits(bm, orc, torch_cuda, scene256, world256)
     acc_k = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
     scene256.render(cam, ok, acc_k)
     acc_d = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
-    scene256.render(cam, bm.FrameParams(W, H, spp=1, max_bounces=15), acc_d)
+    scene256.render(cam, bm.FrameParams(W, H, spp=1, max_bounces=15, flags=bm.BM_FLAG_ORDERED), acc_d)
     torch.cuda.synchronize()
     assert torch.equal(acc_k.view(torch.int32), acc_d.view(torch.int32))
     # 32-bit ticket counters: (chunk, sample) items of a 4K frame at 100 000 spp would wrap them
