@@ -636,6 +636,45 @@ def test_config3_like_streaming_lod_at_scale(bm, orc, torch_cuda):
     scene.close()
 
 
+def test_config3_own_shape_4k_streamed_pixel_items(bm, orc, torch_cuda):
+    """BASELINE config 3 in ITS OWN shape -- 3840x2160, 4 spp, 8 segments, pixel work items, the 2048^3 world streamed in on demand
+    to its steady state (voxel.cuh:228-245, Scene.cpp:200-252) -- i.e. the frame `bench.py --workload config3` times, rendered by the
+    instantiation it runs there: 32 400 tiles take the XCD-aware hand-out (trace_paths<*, true, *>), production frames use helper
+    lanes.  gpu_render renders it instrumented + ordered (hit records), production + ordered (same bits), production + helper
+    lanes (same counts, radiance to 2e-5) and with the K-slot schedule; every 540th row (4 rows x 3840 pixels x 4 samples) is the
+    oracle's, hit records bit for bit."""
+    G, W, H, spp = 2048, 3840, 2160, 4
+    torch = torch_cuda
+    scene = bm.Scene(G, G, device=0)
+    scene.set_queue_capacity(1 << 20)
+    scene.generate()
+    scene.reset_residency()
+    cam, ocam = cameras(bm, orc, G)
+    p = bm.FrameParams(W, H, spp=spp, max_bounces=7)
+    assert ((W + 15) // 16) * ((H + 15) // 16) >= 32000  # scene.cpp frame_constants: this frame takes the XCD-aware hand-out
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    for _ in range(64):
+        scene.render(cam, p, acc)
+        if scene.process_load_queue() == 0:
+            break
+    else:
+        pytest.fail("no streaming steady state")
+    info = scene.info()
+    assert 0 < info["resident_bricks"] < info["total_bricks"]
+    del acc
+    acc, dbg = gpu_render(bm, torch, scene, cam, p)
+    assert scene.process_load_queue() == 0                      # steady state: the frames above asked for nothing new
+    assert np.all(acc[..., 3] == spp)                           # every path of every pixel ended exactly once
+    w = orc.World(G, G)
+    w.reset_device(True)
+    oacc, odbg, _, _ = w.render(ocam, orc.make_frame(W, H, spp=spp, max_bounces=7, band_rows=1, shard_rank=337, shard_count=540), threads=os.cpu_count() or 1)
+    rows = bm.dist.shard_rows(H, 1, 337, 540)
+    assert len(rows) == 4
+    assert np.array_equal(dbg[rows], odbg[rows])
+    assert_radiance(acc[rows], oacc[rows])
+    scene.close()
+
+
 def full_size_sharded_job(bm, orc, torch, scene, cam, ocam, oracle_world, W, H, spp, shards, oracle_row_groups, streamed=True):
     """One multi-GPU job of BASELINE (configs 4 / 5) run shard by shard on this GPU; see the callers."""
     band = bm.dist.DEFAULT_BAND_ROWS
