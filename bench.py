@@ -50,7 +50,7 @@ LIMITER = {
     "config5": "VALU issue (85 G wave instructions at ~19 of 64 lanes: the vector pipes are full); with the XCD-aware hand-out of big frames the fabric sees 30.5 G single-sector "
                "(64 B) read requests/s = 0.63 of the 48 G/s it sustains for random sectors (0.92 before: a third less traffic bought 3 % of time)",
 }
-PROFILE_ROUNDS = ("r04", "r03")  # profiles/<round>_pmc_summary_<workload>.json is where roofline.traffic comes from (newest first)
+PROFILE_ROUNDS = ("r05", "r04", "r03")  # profiles/<round>_pmc_summary_<workload>.json is where roofline.traffic comes from (newest first)
 
 
 def workload(name):
@@ -511,9 +511,13 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
-            **pmc_traffic(args.workload),
+            **counter_figures(args.workload, avg_kernel_s),
             # (the plain instantiation; big frames -- 32000 tiles and more, scene.cpp frame_constants -- take the XCD-aware hand-out)
-            "kernel": "bm::trace_paths<false, true>" if ((W + 15) // 16) * ((state.local_rows + 15) // 16) >= 32000 and os.environ.get("BM_XCD_HANDOUT") != "0" or os.environ.get("BM_XCD_HANDOUT") == "1" else "bm::trace_paths<false, false>",
+            # (the plain instantiation <instrumented = false, XCD-aware hand-out, helper lanes>: big frames -- 32000 tiles and more, scene.cpp
+            # frame_constants -- take the XCD-aware hand-out; production frames run with helper lanes unless BM_FLAG_ORDERED / BM_HELPERS=0)
+            "kernel": "bm::trace_paths<false, %s, %s>" % (
+                "true" if (((W + 15) // 16) * ((state.local_rows + 15) // 16) >= 32000 and os.environ.get("BM_XCD_HANDOUT") != "0") or os.environ.get("BM_XCD_HANDOUT") == "1" else "false",
+                "false" if os.environ.get("BM_HELPERS") == "0" else "true"),
             "kernel_ms_avg": round(float(np.mean(kernel_ms)), 4),
             "algorithmic_bytes_per_launch": alg_bytes / args.steps,
             "bytes_per_actual_ray": round(alg_bytes / max(actual_rays, 1), 1),
@@ -714,6 +718,14 @@ def cpu_baseline(W, H, max_bounces, G, cam):
     }
 
 
+def counter_figures(workload, kernel_s):
+    """pmc_traffic() plus the north-star's own measure: `frac_by_counters` = fabric-side bytes per launch (committed counter passes)
+    / THIS run's kernel duration / 8 TB/s -- next to `frac`, which prices the reference-equivalent bytes."""
+    t = pmc_traffic(workload)
+    t["frac_by_counters"] = round(t["traffic"] / kernel_s / 1e9 / HBM_PEAK_GBS, 5) if t["traffic"] else None
+    return t
+
+
 def pmc_summary_path(workload):
     for rnd in PROFILE_ROUNDS:
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_summary_{workload}.json")
@@ -733,24 +745,29 @@ def limiter_of(workload):
 
 
 def pmc_traffic(workload):
-    """{"traffic": fabric-side bytes per launch, "traffic_source": where it comes from}.  The counters are NOT collected by
-    this run (rocprofv3 PMC needs its own passes, tools/profile_workload.py): the figure is read from the committed summary of
-    the same workload and kernel, and the source is named in the line.  FETCH_SIZE and WRITE_SIZE are KiB.  On gfx950
-    FETCH_SIZE = read requests x 64 B: the guide's x2 applies to full-line coalesced streams only; every read of this
-    kernel is a single 64-byte sector request, for which FETCH_SIZE is exact (profiles/r03_fetch_calibration.txt, measured
-    with tools/ubench/fetch_calib.hip on 1-byte / 4-byte / 64-byte gathers) -- factor 1.0.  Infinity-Cache hits are included."""
+    """{"traffic": fabric-side bytes per launch, "valu_lanes": lanes active per VALU instruction, "valu_insts": wave-level VALU
+    instructions per launch, "traffic_source": where they come from}.  The counters are NOT collected by this run (rocprofv3 PMC
+    needs its own passes, tools/profile_workload.py): the figures are read from the committed summary of the same workload and
+    kernel, and the source is named in the line.  FETCH_SIZE and WRITE_SIZE are KiB.  On gfx950 FETCH_SIZE = read requests x 64 B:
+    the guide's x2 applies to full-line coalesced streams only; every read of this kernel is a single 64-byte sector request, for
+    which FETCH_SIZE is exact (profiles/r03_fetch_calibration.txt, measured with tools/ubench/fetch_calib.hip on 1-byte / 4-byte /
+    64-byte gathers) -- factor 1.0.  Infinity-Cache hits are included."""
+    none = {"traffic": None, "valu_lanes": None, "valu_insts": None, "traffic_source": None}
     path = pmc_summary_path(workload)
     if path is None:
-        return {"traffic": None, "traffic_source": None}
+        return none
     try:
         with open(path) as f:
             d = json.load(f)
         if d.get("workload") != workload:
-            return {"traffic": None, "traffic_source": None}
+            return none
+        lanes = d["SQ_THREAD_CYCLES_VALU"] / d["SQ_ACTIVE_INST_VALU"] if d.get("SQ_ACTIVE_INST_VALU") else None
         return {"traffic": int((1.0 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024),
+                "valu_lanes": round(lanes, 2) if lanes else None,
+                "valu_insts": int(d["SQ_INSTS_VALU"]) if d.get("SQ_INSTS_VALU") else None,
                 "traffic_source": f"profiles/{os.path.basename(path)} (separate rocprofv3 --pmc passes of this workload, not this run)"}
     except (OSError, KeyError, ValueError):
-        return {"traffic": None, "traffic_source": None}
+        return none
 
 
 if __name__ == "__main__":

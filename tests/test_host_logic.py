@@ -157,7 +157,9 @@ def test_bench_helpers_run_without_a_gpu():
         lim = b.limiter_of(wl)
         assert lim["limiter"] and f"_pmc_summary_{wl}.json" in lim["limiter_source"]
     assert b.limiter_of("config1") == {"limiter": None, "limiter_source": None}  # no committed PMC summary: no claim
-    assert b.pmc_traffic("no-such-workload") == {"traffic": None, "traffic_source": None}
+    assert b.pmc_traffic("no-such-workload") == {"traffic": None, "valu_lanes": None, "valu_insts": None, "traffic_source": None}
+    f = b.counter_figures("config2", 1.0e-3)
+    assert 0 < f["frac_by_counters"] < 1 and 10 < f["valu_lanes"] < 64 and f["valu_insts"] > 1e8
 
 
 def test_retired_experiments_stay_out_of_the_kernel_sources():

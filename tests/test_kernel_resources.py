@@ -12,7 +12,9 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "brickmap_amd", "csrc")
-KERNELS = ("_ZN2bm11trace_pathsILb0ELb0E", "_ZN2bm11trace_pathsILb0ELb1E")  # the plain instantiation, and the one with the XCD-aware hand-out
+# trace_paths<instrumented = false, XCD-aware hand-out, helper lanes>: the four production instantiations (the default of production
+# frames is <false, *, true>; BM_FLAG_ORDERED frames run <false, *, false>)
+KERNELS = ("_ZN2bm11trace_pathsILb0ELb0ELb1E", "_ZN2bm11trace_pathsILb0ELb1ELb1E", "_ZN2bm11trace_pathsILb0ELb0ELb0E", "_ZN2bm11trace_pathsILb0ELb1ELb0E")
 
 
 import pytest
