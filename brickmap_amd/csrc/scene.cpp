@@ -220,14 +220,13 @@ int Scene::init(int grid_size, int grid_height) {
 	hipDeviceProp_t prop;
 	BM_HIP(hipGetDeviceProperties(&prop, device_));
 	compute_units_ = prop.multiProcessorCount; // main.cpp:97 sm_cores
-	blocks_per_cu_[0] = trace_blocks_per_cu(false);
-	blocks_per_cu_[1] = trace_blocks_per_cu(true);
+	blocks_per_cu_[0] = blocks_per_cu_[1] = 0; // no cap: every instantiation of the fused kernel runs at its own occupancy (trace.hip launch_trace)
 	blocks_per_cu_k_[0] = trace_k_blocks_per_cu(false);
 	blocks_per_cu_k_[1] = trace_k_blocks_per_cu(true);
 	if (const char* sch = std::getenv("BM_SCHEDULE")) kslot_default_ = std::strcmp(sch, "kslot") == 0;
 	if (const char* cap = std::getenv("BM_TRACE_BLOCKS_PER_CU")) { // experiment knob: fewer resident waves per SIMD (1 block = 1 wave per SIMD)
 		const int n = std::atoi(cap);
-		if (n > 0 && n < blocks_per_cu_[0]) blocks_per_cu_[0] = n;
+		if (n > 0) blocks_per_cu_[0] = n;
 	}
 
 	return alloc_queue();
@@ -979,7 +978,7 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 		launch_trace_k(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, work_counter, instrumented, resident, fs->kslot_scratch, stream);
 	} else {
 		launch_trace(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, work_counter, instrumented,
-					 compute_units_ * blocks_per_cu_[instrumented ? 1 : 0], stream);
+					 compute_units_, blocks_per_cu_[instrumented ? 1 : 0], stream);
 	}
 	BM_HIP(hipGetLastError());
 	BM_HIP(hipEventRecord(ev_stop_[slot], stream));

@@ -37,8 +37,16 @@ namespace bm {
 enum : int { P_GEN = 0, P_EXT_DONE = 1, P_SHD_DONE = 2, P_BOUNCE = 3, P_HELPER = 6 };
 enum : int { ST_IDLE = 4, ST_CONN = 5 };
 
+// Resident waves per SIMD of the production instantiations (the register budget follows: 512 / waves, in steps of 8).  Round 5:
+// with the brick staged straight into LDS (traverse.h brick_dma_to_lds) no lane holds a brick's 16 registers any more -- 84 VGPRs
+// instead of 95 -- and SIX waves fit without a spill (79 VGPRs): config 2 1.066 -> 1.020 ms, config 3 23.4 -> 21.8, config 5
+// 113.7 -> 105.1.  SEVEN waves (72 VGPRs, 5 of them spilled to scratch) change nothing on the cache-resident config 2 and give the
+// big worlds another 2 % (21.4 / 102.9 ms): the instantiation that big frames take anyway (XCD) runs at 7 (profiles/r05_occupancy.txt).
 #ifndef BM_WAVES_PER_SIMD
-#define BM_WAVES_PER_SIMD 5
+#define BM_WAVES_PER_SIMD 6
+#endif
+#ifndef BM_WAVES_PER_SIMD_BIG
+#define BM_WAVES_PER_SIMD_BIG 7
 #endif
 #ifndef BM_ITEM_LANES
 // pixels handed out per ticket: 1 = a refill fills EVERY idle lane (consecutive tickets still walk through a 4x4 chunk row by row).
@@ -104,13 +112,13 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 // written back with atomics as well (the accumulator starts at zero in the lane), so radiance is equal up to summation order.
 template <bool DBG, bool XCD = false, bool HELP = false>
 // (the instrumented variant carries hit records and counters: it gets the registers instead of the occupancy)
-__global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, float4* __restrict__ accum,
+__global__ __launch_bounds__(256, DBG ? 2 : (XCD ? BM_WAVES_PER_SIMD_BIG : BM_WAVES_PER_SIMD)) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, float4* __restrict__ accum,
 												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters,
 												  uint32_t* __restrict__ work_counter) {
 	// the per-frame constants live in device memory (not in the kernel-argument registers): they are read with scalar
 	// loads where they are needed, which keeps the scalar register file free for the scheduler loop
 	const FrameConstants& fc = *fcp;
-	__shared__ unsigned long long lds_brick[8 * 256]; // 16 KiB: one 64-byte brick per thread (brick_to_lds)
+	__shared__ unsigned long long lds_brick[8 * 256]; // 16 KiB: one 64-byte brick per thread (traverse.h brick_dma_to_lds: word k of thread t at u32 word k * 256 + t)
 	const int lane = threadIdx.x & 63;
 	const uint32_t W = static_cast<uint32_t>(fc.width), H = static_cast<uint32_t>(fc.height);
 	const uint32_t total_chunks = static_cast<uint32_t>(fc.tiles_x) * static_cast<uint32_t>(fc.tiles_y) * 16u;
@@ -415,14 +423,13 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					const int n_pairs = min(__popcll(hand_m), __popcll(free_m));
 					const int hrank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hand_m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hand_m), 0u));
 					const int frank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(free_m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(free_m), 0u));
-					float2* const slots = reinterpret_cast<float2*>(lds_brick) + (threadIdx.x & ~63u); // slot k, word pair j at [j * 256 + k]
+					float* const slots = reinterpret_cast<float*>(lds_brick) + (threadIdx.x & ~63u); // word j of slot k at [j * 256 + k]: the wave's own columns
 					const bool gives = hand && hrank < n_pairs, takes = state == ST_IDLE && frank < n_pairs;
 					if (gives) {
-						slots[0 * 256 + hrank] = make_float2(ro.x, ro.y);
-						slots[1 * 256 + hrank] = make_float2(ro.z, rd.x);
-						slots[2 * 256 + hrank] = make_float2(rd.y, rd.z);
-						slots[3 * 256 + hrank] = make_float2(scolor.x, scolor.y);
-						slots[4 * 256 + hrank] = make_float2(scolor.z, __uint_as_float(local_pixel));
+						slots[0 * 256 + hrank] = ro.x; slots[1 * 256 + hrank] = ro.y; slots[2 * 256 + hrank] = ro.z;
+						slots[3 * 256 + hrank] = rd.x; slots[4 * 256 + hrank] = rd.y; slots[5 * 256 + hrank] = rd.z;
+						slots[6 * 256 + hrank] = scolor.x; slots[7 * 256 + hrank] = scolor.y; slots[8 * 256 + hrank] = scolor.z;
+						slots[9 * 256 + hrank] = __uint_as_float(local_pixel);
 						// the owner is done with this shadow ray: what connect would have done next happens now
 						if (terminated) { s++; pstate = P_GEN; need_setup = false; }
 						else { bounces++; ro = hitp; rd = bdir; r.n = pn; shadow = false; }
@@ -431,9 +438,10 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					__builtin_amdgcn_wave_barrier();
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 					if (takes) {
-						const float2 a = slots[0 * 256 + frank], b = slots[1 * 256 + frank], c = slots[2 * 256 + frank], d = slots[3 * 256 + frank], e = slots[4 * 256 + frank];
-						ro = mk(a.x, a.y, b.x); rd = mk(b.y, c.x, c.y); scolor = mk(d.x, d.y, e.x);
-						local_pixel = __float_as_uint(e.y);
+						ro = mk(slots[0 * 256 + frank], slots[1 * 256 + frank], slots[2 * 256 + frank]);
+						rd = mk(slots[3 * 256 + frank], slots[4 * 256 + frank], slots[5 * 256 + frank]);
+						scolor = mk(slots[6 * 256 + frank], slots[7 * 256 + frank], slots[8 * 256 + frank]);
+						local_pixel = __float_as_uint(slots[9 * 256 + frank]);
 						shadow = true;
 						pstate = P_HELPER;
 						need_setup = true;
@@ -496,6 +504,24 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			if (BM_PRIO) __builtin_amdgcn_s_setprio(BM_PRIO_B);
 			if (BM_TIMED) { runsB++; lanesB += nB; }
 			// ================= phase B: resolve non-empty cells (index word, LoD / 8^3 bitmask DDA, streaming request)
+#ifdef BM_SHARE_PROBE
+			// profiling build (-DBM_PHASE_TIMING -DBM_SHARE_PROBE, tools/share_probe.py): how often do lanes of one candidate pass test the
+			// SAME brick cell -- what broadcasting one staged brick across the wavefront (the north-star's LDS sentence) could share?
+			// det[5] = candidate passes, det[6] = those in which at least two lanes are in the same cell, det[7] = lanes whose cell a
+			// lower lane of the pass tests as well (their brick fetch + staging is what a broadcast would save)
+			{
+				const bool cand = state == ST_CAND;
+				const uint32_t cell_id = r.p - r.field_off;
+				bool dup = false;
+				for (int l = 0; l < 63; ++l) {
+					const uint32_t other = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cell_id), l));
+					const bool other_cand = (__ballot(cand) >> l) & 1ull;
+					dup = dup || (cand && other_cand && lane > l && other == cell_id);
+				}
+				const int n_dup = __popcll(__ballot(dup));
+				if (__ballot(cand) != 0ull) { det[5] += 1; det[6] += n_dup ? 1 : 0; det[7] += static_cast<unsigned long long>(n_dup); }
+			}
+#endif
 #ifdef BM_PHASE_TIMING
 			uint32_t walk_trips = 0;
 			if (state == ST_CAND) {
@@ -506,7 +532,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 #endif
 				state = (st == ST_NEED && shadow) ? ST_CONN : st;
 			}
-#ifdef BM_PHASE_TIMING
+#if defined(BM_PHASE_TIMING) && !defined(BM_SHARE_PROBE)
 			{ // longest 8^3 walk of this pass (= its loop length) and the lanes' own walk lengths
 				uint32_t mx = walk_trips, sum = walk_trips;
 				for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(mx, off, 64); mx = o > mx ? o : mx; sum += __shfl_xor(sum, off, 64); }
@@ -647,22 +673,33 @@ __global__ void debug_sky_kernel(const FrameConstants fc, int n, const float* __
 }
 
 // ---- host-callable launchers (kernels.h)
-int trace_blocks_per_cu(bool instrumented) {
-	int n = 0;
-	const hipError_t e = instrumented ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<true>, 256, 0)
-									  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<false>, 256, 0);
-	return e == hipSuccess && n > 0 ? n : 1;
+// resident 256-thread workgroups per compute unit of one instantiation (asked once per instantiation)
+template <bool DBG, bool XCD, bool HELP>
+static int occupancy_of() {
+	static const int cached = [] {
+		int n = 0;
+		const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<DBG, XCD, HELP>, 256, 0);
+		return e == hipSuccess && n > 0 ? n : 1;
+	}();
+	return cached;
+}
+int trace_blocks_per_cu(bool instrumented, bool xcd, bool help) {
+	if (instrumented) return xcd ? (help ? occupancy_of<true, true, true>() : occupancy_of<true, true, false>()) : (help ? occupancy_of<true, false, true>() : occupancy_of<true, false, false>());
+	return xcd ? (help ? occupancy_of<false, true, true>() : occupancy_of<false, true, false>()) : (help ? occupancy_of<false, false, true>() : occupancy_of<false, false, false>());
 }
 
 // Persistent launch: exactly as many 256-thread workgroups as the device keeps resident (compute_units x
 // blocks per CU); the waves pull 4x4-pixel chunks from *work_counter, which must be zero at launch.
 void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameConstants* fc_dev, float* accum, uint32_t* dbg, DeviceCounters* counters,
-				  uint32_t* work_counter, bool instrumented, int resident_blocks, hipStream_t stream) {
+				  uint32_t* work_counter, bool instrumented, int compute_units, int blocks_per_cu_cap, hipStream_t stream) {
 	const long long chunks = static_cast<long long>(fc.tiles_x) * fc.tiles_y * 16;
 	if (chunks <= 0) return;
+	const bool xcd = fc.xcd_handout != 0;
+	int per_cu = trace_blocks_per_cu(instrumented, xcd, fc.helpers != 0); // what THIS instantiation keeps resident
+	if (blocks_per_cu_cap > 0 && per_cu > blocks_per_cu_cap) per_cu = blocks_per_cu_cap;
+	const long long resident_blocks = static_cast<long long>(compute_units) * per_cu;
 	long long blocks = (chunks + 15) / 16; // never more workgroups than 64-pixel groups
 	if (blocks > resident_blocks) blocks = resident_blocks;
-	const bool xcd = fc.xcd_handout != 0;
 	float4* const acc4 = reinterpret_cast<float4*>(accum);
 	const dim3 grid(static_cast<unsigned>(blocks)), block(256);
 #ifdef BM_PHASE_TIMING

@@ -85,17 +85,43 @@ __device__ __forceinline__ void brick_to_lds(unsigned long long* lds_brick, cons
 	lds_brick[7 * 256 + t] = static_cast<unsigned long long>(b.q3.z) | (static_cast<unsigned long long>(b.q3.w) << 32);
 }
 
+// LDS-direct staging (the default of the fused and the queue kernels): the brick never passes through registers.  gfx950's
+// global_load_lds_dword moves 4 bytes per lane from the lane's own global address to LDS at M0 + offset + lane * 4 -- lane-
+// contiguous words, which is exactly a bank-conflict-free layout: word k (0...15) of thread t's brick at word k * 256 + t of
+// the staging area.  Sixteen such loads (M0 steps by 1020 bytes between them: the instruction offset, k * 4, counts for the
+// global AND the LDS address) replace four 16-byte loads + a wait + eight ds_write_b64; a z-slice is the two words 2z, 2z + 1,
+// one ds_read2st64_b32.  The staging sits on the candidate pass's critical path -- staging the brick a second time cost 2.9 % of
+// the 1080p frame (profiles/r05_brick_staging.txt) -- and inactive lanes write nothing, as with any masked store.
+#ifndef BM_LDS_DMA
+#define BM_LDS_DMA 1
+#endif
+typedef __attribute__((address_space(1))) const void* bm_global_cptr;
+typedef __attribute__((address_space(3))) void* bm_lds_ptr;
+__device__ __forceinline__ void brick_dma_to_lds(unsigned long long* lds_brick, const uint32_t* brick_words) {
+	const uint32_t wave_off = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((threadIdx.x & ~63u) * 4u))); // this wave's 64 columns
+	char* const base = reinterpret_cast<char*>(lds_brick) + wave_off;
+#define BM_DMA_WORD(k) __builtin_amdgcn_global_load_lds((bm_global_cptr)brick_words, (bm_lds_ptr)(base + (k) * 1020), 4, (k) * 4, 0)
+	BM_DMA_WORD(0); BM_DMA_WORD(1); BM_DMA_WORD(2); BM_DMA_WORD(3); BM_DMA_WORD(4); BM_DMA_WORD(5); BM_DMA_WORD(6); BM_DMA_WORD(7);
+	BM_DMA_WORD(8); BM_DMA_WORD(9); BM_DMA_WORD(10); BM_DMA_WORD(11); BM_DMA_WORD(12); BM_DMA_WORD(13); BM_DMA_WORD(14); BM_DMA_WORD(15);
+#undef BM_DMA_WORD
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the loads write LDS: their data is there once they have returned
+}
+
 // OVERLAY (trace_k.hip): the brick is staged in four 16-byte chunks 4 KiB apart that belong to the calling thread alone
 // (`lds_brick` points at the first): slice z is the 64-bit half (z & 1) of chunk z >> 1.
 template <bool OVERLAY>
 __device__ __forceinline__ unsigned long long brick_slice(const unsigned long long* lds_brick, uint32_t z) {
 	if (OVERLAY) return lds_brick[(z >> 1) * 512u + (z & 1u)];
+	if (BM_LDS_DMA) {
+		const uint32_t* w = reinterpret_cast<const uint32_t*>(lds_brick) + z * 512u + threadIdx.x;
+		return static_cast<unsigned long long>(w[0]) | (static_cast<unsigned long long>(w[256]) << 32);
+	}
 	return lds_brick[z * 256u + threadIdx.x];
 }
 template <int N, bool DBG, bool OVERLAY = false>
 __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy, int sz, float dx, float dy, float dz, f3& normal, float& distance,
 											   const BrickRegs& brick, uint32_t byte, int& sub_id, Tally& tally, unsigned long long* lds_brick = nullptr,
-											   uint32_t* trips = nullptr) {
+											   uint32_t* trips = nullptr, const uint32_t* brick_words = nullptr) {
 	int px = static_cast<int>(origin.x), py = static_cast<int>(origin.y), pz = static_cast<int>(origin.z);
 	const float cbx = dir.x > 0.f ? static_cast<float>(px + 1) : static_cast<float>(px);
 	const float cby = dir.y > 0.f ? static_cast<float>(py + 1) : static_cast<float>(py);
@@ -123,6 +149,8 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 		if (OVERLAY) {
 			uint4* q = reinterpret_cast<uint4*>(lds_brick);
 			q[0] = brick.q0; q[256] = brick.q1; q[512] = brick.q2; q[768] = brick.q3;
+		} else if (BM_LDS_DMA) {
+			brick_dma_to_lds(lds_brick, brick_words);
 		} else {
 			brick_to_lds(lds_brick, brick);
 		}
@@ -461,8 +489,8 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 		int sub = 0;
 		const f3 o8 = (r.o + r.d * new_distance) * 8.f - r.n * kEpsilon;
 		const uint4* bq = reinterpret_cast<const uint4*>(sc.brick_arena + (static_cast<size_t>(pool + (index & kIndexBits)) << 4));
-		brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3];
-		if (intersect_grid<8, DBG, OVERLAY>(o8, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick, walk_trips)) {
+		if (OVERLAY || !BM_LDS_DMA) { brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3]; }
+		if (intersect_grid<8, DBG, OVERLAY>(o8, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick, walk_trips, reinterpret_cast<const uint32_t*>(bq))) {
 			r.distance = new_distance * 8.f + sub_distance + r.tminn;
 			if (DBG) { info.level = 2; info.sub_id = sub; }
 			r.hit = true;

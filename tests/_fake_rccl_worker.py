@@ -33,7 +33,7 @@ def main():
     scene = bm.Scene(G, G, device=0).generate().preload_all()
     cam = bm.Camera(position=(G / 2, G / 8, 0.8 * G), horizontal_angle=0.8, vertical_angle=-0.5).update()
     state = bm.State(W, H, device=0, band_rows=band, shard_rank=rank, shard_count=world)
-    p = bm.FrameParams(W, H, spp=2, max_bounces=3, band_rows=band, shard_rank=rank, shard_count=world)
+    p = bm.FrameParams(W, H, spp=2, max_bounces=3, band_rows=band, shard_rank=rank, shard_count=world, flags=bm.BM_FLAG_ORDERED)  # ordered sums: the gathered frame is compared bit for bit
     frame = torch.full((H, W, 4), float("nan"), dtype=torch.float32, device="cuda:0") if rank == root else None
     for step in range(2):  # two frames through the same communicator (the root's stacked buffer is reused)
         scene.render(cam, p, state.blit_buffer)
@@ -42,7 +42,7 @@ def main():
     if rank == root:
         want = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
         for step in range(2):
-            scene.render(cam, bm.FrameParams(W, H, spp=2, max_bounces=3), want)
+            scene.render(cam, bm.FrameParams(W, H, spp=2, max_bounces=3, flags=bm.BM_FLAG_ORDERED), want)
         torch.cuda.synchronize()
         assert torch.equal(frame.view(torch.int32), want.view(torch.int32)), "gathered frame differs from the unsharded render"
     # the sample decomposition's exchange: every rank contributes rank + 1

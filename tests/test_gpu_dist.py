@@ -43,10 +43,10 @@ def test_root_assembly_kernel_with_three_ranks_on_one_gpu():
     scene = bm.Scene(G, G, device=0).generate().preload_all()
     cam = bm.Camera(position=(G / 2, G / 8, 0.8 * G), horizontal_angle=0.8, vertical_angle=-0.5).update()
     full = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
-    scene.render(cam, bm.FrameParams(W, H, spp=2, max_bounces=3), full)
+    scene.render(cam, bm.FrameParams(W, H, spp=2, max_bounces=3, flags=bm.BM_FLAG_ORDERED), full)  # (ordered sums: compared bit for bit below)
     shards = []
     for r in range(world):
-        p = bm.FrameParams(W, H, spp=2, max_bounces=3, band_rows=band, shard_rank=r, shard_count=world)
+        p = bm.FrameParams(W, H, spp=2, max_bounces=3, band_rows=band, shard_rank=r, shard_count=world, flags=bm.BM_FLAG_ORDERED)
         a = torch.zeros((bm.local_rows(p), W, 4), dtype=torch.float32, device="cuda:0")
         scene.render(cam, p, a)
         shards.append(a)

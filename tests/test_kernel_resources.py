@@ -1,7 +1,7 @@
 """Guard rails for the production kernel's compiled shape (CPU only: hipcc cross-compiles gfx950 without a GPU).
 
-bm::trace_paths<false> is bound by vector-instruction issue at 5 waves per SIMD.  Two things silently cost
-10 % or more and have both happened: a register budget above 96 VGPRs (one wave per SIMD less, or spills), and the backend
+bm::trace_paths<false, ...> is bound by vector-instruction issue at 6 waves per SIMD (7 for big frames).  Two things
+silently cost 5-10 % and have both happened: a register budget one step too high (one wave per SIMD less, or spills), and the backend
 linearising the scheduler loop's scalar branches again, which keeps every lane's state in two register sets and copies
 one onto the other around every pass (a few hundred extra v_mov; a small change to the loop's control flow is enough).
 """
@@ -30,9 +30,15 @@ def test_production_kernel_keeps_its_register_budget_and_its_shape(KERNEL):
     def field(name):
         return int(re.search(name + r": (\d+)", block).group(1))
 
-    assert field("VGPRs") <= 96, "more than 96 VGPRs: 4 waves per SIMD instead of 5"
-    assert field("VGPRs Spill") == 0 and field(r"ScratchSize \[bytes/lane\]") == 0
-    assert field(r"Occupancy \[waves/SIMD\]") == 5
+    big = "ILb0ELb1E" in KERNEL  # the XCD instantiation big frames take: 7 waves per SIMD, the others 6 (trace.hip BM_WAVES_PER_SIMD*)
+    if big:
+        assert field("VGPRs") <= 72 and field(r"Occupancy \[waves/SIMD\]") == 7
+        assert field("VGPRs Spill") <= 6 and field(r"ScratchSize \[bytes/lane\]") <= 32, "7 waves were measured with 5 spilled registers; more was not"
+    else:
+        assert field("VGPRs") <= 80, "more than 80 VGPRs: 5 waves per SIMD instead of 6"
+        assert field("VGPRs Spill") == 0 and field(r"ScratchSize \[bytes/lane\]") == 0
+        assert field(r"Occupancy \[waves/SIMD\]") == 6
+    assert field(r"LDS Size \[bytes/block\]") == 16384
     lines = open(os.path.join(CSRC, "build", "trace-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
     start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL) and ":" in l)
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
@@ -40,6 +46,6 @@ def test_production_kernel_keeps_its_register_budget_and_its_shape(KERNEL):
     valu = sum(c for o, c in ops.items() if o.startswith("v_"))
     movs = sum(c for o, c in ops.items() if o.startswith("v_mov_b"))
     packed = sum(c for o, c in ops.items() if o.startswith("v_pk_"))
-    assert movs <= 260, f"{movs} register copies in {valu} VALU instructions: the scheduler loop was structurized again (tools/isa_movs.py)"
+    assert movs <= 275, f"{movs} register copies in {valu} VALU instructions: the scheduler loop was structurized again (tools/isa_movs.py)"
     assert packed == 0, "packed fp32 operations: SLP vectorisation is back (they cost two plain operations each and pair registers)"
     assert valu <= 2100, f"{valu} VALU instructions"
