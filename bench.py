@@ -43,7 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# what bounds trace_paths on each workload (DESIGN.md 5; profiles/r0x_pmc_summary_<workload>.json, profiles/r03_fetch_calibration.txt)
+# what bounds trace_paths on each workload (DESIGN.md 4; profiles/r0x_pmc_summary_<workload>.json, profiles/r03_fetch_calibration.txt)
 LIMITER = {
     "config2": "VALU issue: the vector pipes are busy for >= 85 % of the launch with ~20 of 64 lanes active per instruction; the scene (93 MiB) stays in L2 / Infinity Cache",
     "config3": "VALU issue, with 0.40 G single-sector reads reaching the fabric per launch (TCC hit 75 %; XCD-aware hand-out)",
@@ -173,7 +173,7 @@ def main():
         return bench_wavefront(args, bm, torch, np, scene, cam, accum, W, H, max_bounces, n_super, G, streaming, build_s)
 
     # Everything resident: pipeline consecutive frames over `pipeline` streams.  A fifth of a 1080p-sample frame is the drain
-    # (waves working their last paths off); the next frame's workgroups fill the freed slots.  Every stream
+    # (waves working their last paths off, docs/HISTORY.md 5.2); the next frame's workgroups fill the freed slots.  Every stream
     # has its OWN accumulation buffer (frame i adds into buffer i % pipeline), so no two frames in flight touch the same
     # pixel record and the default, deterministic accumulation can be used; the image is the sum of the buffers.
     pipeline = max(1, args.pipeline) if not streaming else 1
@@ -741,7 +741,7 @@ def limiter_of(workload):
     path = pmc_summary_path(workload)
     if workload not in LIMITER or path is None or os.environ.get("BM_SCHEDULE"):
         return {"limiter": None, "limiter_source": None}
-    return {"limiter": LIMITER[workload], "limiter_source": f"profiles/{os.path.basename(path)} + DESIGN.md 5 (default build, default schedule)"}
+    return {"limiter": LIMITER[workload], "limiter_source": f"profiles/{os.path.basename(path)} + DESIGN.md 4 (default build, default schedule)"}
 
 
 def pmc_traffic(workload):

@@ -3,7 +3,7 @@
 //
 // Why.  trace.hip keeps one path per lane in registers.  A wave's 64 paths want different things -- a walk pass, a
 // candidate pass, a shade pass -- and a pass costs the same with 15 or 64 lanes active, so the vector pipes run saturated at
-// ~20 of 64 lanes per instruction (the bound of a one-path-per-lane state machine is ~1/k for k pass types of
+// ~20 of 64 lanes per instruction (docs/HISTORY.md 5.4: the bound of a one-path-per-lane state machine is ~1/k for k pass types of
 // equal weight).  Here every lane owns K paths ("slots"); a pass serves a lane if ANY of its slots wants it, so a pass that
 // one path in three wants is wanted by 1 - (2/3)^K of the lanes.  Two paths per lane in REGISTERS cost the occupancy that hides
 // the walk's load latencies (round 2: 170-250 VGPRs, 2.6 ms); with the state in LDS a pass holds only its own working set:
@@ -19,7 +19,7 @@
 //   registers across passes: ONE word of one-hot slot states per lane (a byte per slot) and the wave-uniform scheduler state.
 //
 // K * 64 bytes of LDS per lane bound the occupancy: K = 2 -> 4 waves per SIMD, K = 3 -> 3, K = 4 -> 2 (160 KiB per CU).
-// tools/sim/sched_sim.cpp replays the real paths of bench config 2 through this organisation: see DESIGN.md 5.5.
+// tools/sim/sched_sim.cpp replays the real paths of bench config 2 through this organisation: see docs/HISTORY.md 5.5.
 //
 // Per-ray arithmetic is that of trace.hip -- the same device functions of traverse.h / jump.h, the same operands in the same
 // order -- so hit records are bit-identical to the CPU oracle; scheduling changes WHEN a path's operations happen, never what
@@ -485,7 +485,7 @@ int trace_k_blocks_per_cu(bool instrumented) {
 	int n = 0;
 	const hipError_t e = instrumented ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths_k<true>, 256, 0)
 									  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths_k<false>, 256, 0);
-#ifdef BM_K_MAX_BLOCKS // occupancy experiments: fewer resident workgroups per CU than the LDS allows
+#ifdef BM_K_MAX_BLOCKS // occupancy experiments (docs/HISTORY.md 5.5): fewer resident workgroups per CU than the LDS allows
 	if (n > BM_K_MAX_BLOCKS) n = BM_K_MAX_BLOCKS;
 #endif
 	return e == hipSuccess && n > 0 ? n : 1;

@@ -44,7 +44,7 @@ private:
 	bool slot_used_[kConstantsRing] = {};
 	bool timed_ = false;
 	// resident workgroups per CU of the persistent kernels: the walk is instruction-bound, throughput saturates at 5 waves
-	// per SIMD (2 / 3 / 4 / 5 / 6: 1546 / 1851 / 2014 / 2072 / 2062 Mrays/s) and a 6th only lengthens the tail
+	// per SIMD (2 / 3 / 4 / 5 / 6: 1546 / 1851 / 2014 / 2072 / 2062 Mrays/s, docs/HISTORY.md 5b) and a 6th only lengthens the tail
 	static constexpr int kMaxBlocksPerCu = 5;
 	int blocks_per_cu_[2][2] = {{0, 0}, {0, 0}}; // [connect][instrumented]
 };

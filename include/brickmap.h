@@ -115,7 +115,7 @@ typedef struct bm_counters {
 } bm_counters;
 
 /* wave-scheduler statistics of the instrumented kernel (BM_FLAG_COUNTERS): how often each phase of the
- * per-wave scheduler ran and with how many of the 64 lanes active (DESIGN.md "Wave scheduler") */
+ * per-wave scheduler ran and with how many of the 64 lanes active */
 typedef struct bm_sched_stats {
 	uint64_t step_runs, step_lanes;           /* phase A: brick-grid DDA moves       */
 	uint64_t candidate_runs, candidate_lanes; /* phase B: index word + bitmask DDA   */

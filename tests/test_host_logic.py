@@ -176,7 +176,7 @@ def test_retired_experiments_stay_out_of_the_kernel_sources():
 
 
 def test_scheduler_simulator_builds_and_runs(tmp_path, orc):
-    """tools/sim/sched_sim.cpp (the model behind DESIGN.md 5.5) stays buildable against the product's jump.h / world.cpp and the
+    """tools/sim/sched_sim.cpp (the model behind docs/HISTORY.md 5.5) stays buildable against the product's jump.h / world.cpp and the
     oracle, and on a sampled frame more paths per lane mean fuller passes."""
     import re
     import subprocess

@@ -1,6 +1,6 @@
 """Guard rails for the production kernel's compiled shape (CPU only: hipcc cross-compiles gfx950 without a GPU).
 
-bm::trace_paths<false, ...> is bound by vector-instruction issue at 6 waves per SIMD (7 for big frames; DESIGN.md 5).  Two things
+bm::trace_paths<false, ...> is bound by vector-instruction issue at 6 waves per SIMD (7 for big frames; DESIGN.md 4.4).  Two things
 silently cost 5-10 % and have both happened: a register budget one step too high (one wave per SIMD less, or spills), and the backend
 linearising the scheduler loop's scalar branches again, which keeps every lane's state in two register sets and copies
 one onto the other around every pass (a few hundred extra v_mov; a small change to the loop's control flow is enough).

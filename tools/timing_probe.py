@@ -29,7 +29,7 @@ if csum:
 if d["brick_passes"]:
     print("candidate passes that walked a brick: %d, loop length (longest walk of the pass) %.2f cells, lanes' own walks %.2f cells on %.1f lanes" %
           (d["brick_passes"], d["brick_loop_trips"] / d["brick_passes"], d["brick_lane_steps"] / max(1, s["candidate_lanes"]), s["candidate_lanes"] / max(1, s["candidate_runs"])))
-# the one-path-per-lane bound: with pass types s of cost c_s (issue time of one pass) that a ray needs o_s
+# the one-path-per-lane bound (docs/HISTORY.md 5.4): with pass types s of cost c_s (issue time of one pass) that a ray needs o_s
 # times, the time per ray on a 64-lane wave is sum(o_s c_s / n_s) with sum(n_s) <= 64 lanes to share: minimal for
 # n_s ~ sqrt(o_s c_s), i.e. lane utilisation <= sum(w_s) / (sum(sqrt(w_s)))^2 with w_s = o_s c_s
 import math
