@@ -189,14 +189,20 @@ int Scene::init(int grid_size, int grid_height) {
 		set_error("grid_size and grid_height must be positive multiples of 128 voxels");
 		return BM_EINVAL;
 	}
-	if (world.dims.cells > 1024 || world.dims.cells_height > 992) { // the traversal packs a brick cell into 11 + 11 + 10 bits (traverse.h)
-		set_error("worlds larger than 8192 x 8192 x 7936 voxels are not supported");
+	if (world.dims.cells > 1024 || world.dims.cells_height > 1024) { // candidates take 24-bit products of brick coordinates and of their distance to the camera (traverse.h)
+		set_error("worlds larger than 8192 voxels a side are not supported");
 		return BM_EINVAL;
 	}
-	// the walk addresses the 8 planes of the octant cube field with one 32-bit offset (traverse.h field_lookup)
-	if (8ull * static_cast<uint64_t>(world.dims.cells + 2) * (world.dims.cells + 2) * (world.dims.cells_height + 2) >= (1ull << 32)) {
-		set_error("world too large: the octant cube field (8 bytes per brick cell) must stay below 4 GiB");
-		return BM_EINVAL;
+	// the walk keeps a ray's cell as ONE 32-bit byte offset into the 8 planes of the octant cube field, whose rows are padded to a
+	// power of two (traverse.h cell_offset; allocate_device lays it out): 8 x (cells_h + 2) x (cells + 2) x 2^shift bytes < 4 GiB
+	{
+		int shift = 2;
+		while ((1 << shift) < world.dims.cells + 2) ++shift;
+		const uint64_t plane = (static_cast<uint64_t>(world.dims.cells + 2) << shift) * static_cast<uint64_t>(world.dims.cells_height + 2);
+		if (plane * 8 >= (1ull << 32)) {
+			set_error("world too large: the octant cube field (8 planes, rows padded to a power of two) must stay below 4 GiB");
+			return BM_EINVAL;
+		}
 	}
 	BM_HIP(hipSetDevice(device_));
 	BM_HIP(hipStreamCreateWithFlags(&load_stream_, hipStreamNonBlocking));

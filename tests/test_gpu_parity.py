@@ -295,7 +295,7 @@ def test_non_cubic_world(bm, orc, torch_cuda):
 
 
 @pytest.mark.parametrize("dims,pos,angles", [
-    ((128, 7936), (40.0, 40.0, 5900.0), (0.4, -1.5)),      # tallest world the packed cell register allows (992 bricks): down the shaft
+    ((128, 7936), (40.0, 40.0, 5900.0), (0.4, -1.5)),      # a very tall world (992 bricks): down the shaft
     ((128, 7936), (-900.0, 64.0, 3500.0), (1.5, 0.05)),    # camera outside, looking across the column below the terrain top
     ((8192, 128), (8000.0, 8100.0, 120.0), (3.9, -0.12)),  # widest world (1024 bricks): the far corner, looking back
 ])
@@ -523,9 +523,11 @@ def test_errors_are_reported_not_fatal(bm, torch_cuda):
     L = _lib.load()
     h = C.c_void_p()
     assert L.bm_scene_create(0, 100, 128, C.byref(h)) == 10001 and b"multiples of 128" in L.bm_last_error_string()
-    # the walk packs a brick cell into 11 + 11 + 10 bits: larger worlds are refused, not mis-traced
+    # a ray's cell is one 32-bit offset into the padded cube field, candidates take 24-bit products of brick coordinates: larger worlds
+    # are refused, not mis-traced
     assert L.bm_scene_create(0, 8192 + 128, 128, C.byref(h)) == 10001 and b"not supported" in L.bm_last_error_string()
-    assert L.bm_scene_create(0, 1024, 8064, C.byref(h)) == 10001 and b"not supported" in L.bm_last_error_string()
+    assert L.bm_scene_create(0, 1024, 8192 + 128, C.byref(h)) == 10001 and b"not supported" in L.bm_last_error_string()
+    assert L.bm_scene_create(0, 8192, 8192, C.byref(h)) == 10001 and b"4 GiB" in L.bm_last_error_string()
     s = bm.Scene(128, 128, device=0)
     with pytest.raises(bm.BrickmapError):
         s.preload_all()  # not generated yet
