@@ -47,7 +47,17 @@ float sun_intensity(float zenith_cos) {
 }
 } // namespace
 
-int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp, FrameConstants* fc) {
+int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_in, FrameConstants* fc, bool hit_records, bool kslot) {
+	if (!fp_in) { set_error("null argument"); return BM_EINVAL; }
+	// Which frames are ORDERED (every pixel's events accumulated in path order by one lane, one plain write-back: reproducible sums)?
+	// Those that ask for it, those that write hit records, K-slot frames, primary-only frames.  Every other frame -- the production
+	// default -- may add in any order, like the reference's own atomicAdds (kernel.cu:319-322,341-343): it runs with helper lanes
+	// (trace.hip HELP) and, when a pixel has several samples, with (4x4 chunk, sample) work items: shorter items, a shorter tail,
+	// coherent neighbouring samples (1080p at 4 spp 4.0 -> 3.4 ms, config 3 -4 %).  BM_HELPERS=0 / 1 overrides helper lanes (A/B runs).
+	bm_frame_params promoted = *fp_in;
+	const bool ordered = (promoted.flags & (BM_FLAG_ORDERED | BM_FLAG_PRIMARY_ONLY)) != 0 || hit_records || kslot;
+	if (!ordered && promoted.spp >= 2) promoted.flags |= BM_FLAG_SAMPLE_ITEMS;
+	const bm_frame_params* const fp = &promoted;
 	if (!cam || !fp || !fc) { set_error("null argument"); return BM_EINVAL; }
 	if (fp->width <= 0 || fp->height <= 0 || fp->spp < 0 || fp->max_bounces < 0 || fp->band_rows <= 0 || fp->shard_count <= 0 ||
 		fp->shard_rank < 0 || fp->shard_rank >= fp->shard_count) {
@@ -127,11 +137,10 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp,
 	if (xcd_override == 0 || xcd_override == 1) fc->xcd_handout = xcd_override;
 	static const int refill_override = [] { const char* e = std::getenv("BM_REFILL_MIN"); return e ? std::atoi(e) : 0; }(); // tuning runs
 	if (refill_override >= 1 && refill_override <= 64) fc->refill_min = refill_override;
-	// shadow rays on helper lanes (trace.hip HELP): on unless the caller wants ordered sums; render() turns it off for frames that
-	// write hit records.  BM_HELPERS=0 / 1 overrides (A/B runs, tests).
-	fc->helpers = (fp->flags & (BM_FLAG_ORDERED | BM_FLAG_PRIMARY_ONLY)) ? 0 : 1;
+	// shadow rays on helper lanes (trace.hip HELP): every frame that is not ordered (above)
+	fc->helpers = ordered ? 0 : 1;
 	static const int help_override = [] { const char* e = std::getenv("BM_HELPERS"); return e ? std::atoi(e) : -1; }();
-	if (help_override == 0 || (help_override == 1 && !(fp->flags & BM_FLAG_PRIMARY_ONLY))) fc->helpers = help_override;
+	if (help_override == 0 || (help_override == 1 && !ordered)) fc->helpers = help_override;
 	// The hand-out counts tickets in 32 bits (trace.hip: `my_tickets`, `base + want`).  The busiest counter owns a 1/8 share of the
 	// units -- groups of four chunks, or 256x256-pixel super-tiles of 4096 chunks -- times 16 tickets per chunk and, with (chunk,
 	// sample) items, per sample; every wave may overshoot a used-up counter once by up to 64.  Refuse what would wrap.
@@ -942,8 +951,8 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
 	if (!accum) { set_error("null accumulation buffer"); return BM_EINVAL; }
 	FrameConstants fc;
-	if (int e = fill_frame_constants(cam, fp, &fc)) return e;
-	if (dbg) fc.helpers = 0; // hit records are per pixel, in path order: the owner traces every ray of its paths
+	const bool kslot = kslot_default_ || (fp && (fp->flags & BM_FLAG_KSLOT));
+	if (int e = fill_frame_constants(cam, fp, &fc, dbg != nullptr, kslot)) return e;
 	BM_HIP(hipSetDevice(device_));
 	// `stream` is used as given: nullptr is HIP's default stream (what the reference's <<<>>> launches use), which is
 	// ordered with the caller's other default-stream work (e.g. torch's fill kernels on the accumulation buffer).

@@ -63,7 +63,8 @@ public:
 	World world;
 	int device() const { return device_; }
 
-	static int fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp, FrameConstants* fc);
+	// hit_records: the frame writes per-pixel hit records; kslot: it runs the K-slot schedule -- both make it an ORDERED frame (scene.cpp)
+	static int fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp, FrameConstants* fc, bool hit_records = false, bool kslot = false);
 
 private:
 	int allocate_device();

@@ -55,8 +55,10 @@ extern "C" {
                                    one plain store: a frame's sums are reproducible bit for bit.  WITHOUT this flag (the default) a wave
                                    may hand a path's shadow ray to one of its idle lanes (csrc/trace.hip HELP): the same rays are
                                    traced, the unoccluded sun light is added to the pixel with float atomics like the reference's
-                                   connect does (kernel.cu:341-343), and radiance is equal up to summation order (~1e-7 relative).
-                                   Frames that write hit records (debug_dev != NULL) and K-slot frames are always ordered. */
+                                   connect does (kernel.cu:341-343), and radiance is equal up to summation order (~1e-7 relative); and a
+                                   frame with several samples per pixel is scheduled as (4x4 chunk, sample) work items, as if
+                                   BM_FLAG_SAMPLE_ITEMS were set (1080p at 4 spp: 3.4 ms against 4.0).
+                                   Frames that write hit records (debug_dev != NULL), K-slot frames and primary-only frames are always ordered. */
 
 typedef struct bm_scene bm_scene; /* Scene + its GPUScene view (Scene.h:7-44), one GPU */
 

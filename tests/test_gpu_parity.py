@@ -638,11 +638,11 @@ def test_config3_like_streaming_lod_at_scale(bm, orc, torch_cuda):
     scene.close()
 
 
-def test_config3_own_shape_4k_streamed_pixel_items(bm, orc, torch_cuda):
+def test_config3_own_shape_4k_streamed(bm, orc, torch_cuda):
     """BASELINE config 3 in ITS OWN shape -- 3840x2160, 4 spp, 8 segments, pixel work items, the 2048^3 world streamed in on demand
     to its steady state (voxel.cuh:228-245, Scene.cpp:200-252) -- i.e. the frame `bench.py --workload config3` times, rendered by the
     instantiation it runs there: 32 400 tiles take the XCD-aware hand-out (trace_paths<*, true, *>), production frames use helper
-    lanes.  gpu_render renders it instrumented + ordered (hit records), production + ordered (same bits), production + helper
+    lanes and, having four samples per pixel, (chunk, sample) work items; the ordered frames trace pixel items.  gpu_render renders it instrumented + ordered (hit records), production + ordered (same bits), production + helper
     lanes (same counts, radiance to 2e-5) and with the K-slot schedule; every 540th row (4 rows x 3840 pixels x 4 samples) is the
     oracle's, hit records bit for bit."""
     G, W, H, spp = 2048, 3840, 2160, 4
@@ -927,6 +927,7 @@ for k in range(400):
     if idle >= 2: break
 assert idle >= 2
 i = s.info()
+p.flags |= bm.BM_FLAG_ORDERED  # (the frame whose sum is compared: reproducible sums)
 out = torch.zeros_like(acc); s.render(cam, p, out); torch.cuda.synchronize()
 print("RESULT", i["arena_virtual"], i["arena_growths"], i["arena_copy_growths"], i["resident_bricks"], float(out.double().sum().item()))
 """ % root

@@ -524,6 +524,11 @@ int main(int argc, char** argv) {
 		g_tile_perm.resize(cost.size());
 		if (!strcmp(ord, "lpt")) { std::stable_sort(cost.begin(), cost.end(), [](auto& a, auto& b) { return a.first > b.first; }); for (size_t i = 0; i < cost.size(); ++i) g_tile_perm[i] = cost[i].second; }
 		else if (!strcmp(ord, "skylast")) { size_t k = 0; for (auto& c : cost) if (c.first > 1.0) g_tile_perm[k++] = c.second; P.split_tiles = (int)k; for (auto& c : cost) if (c.first <= 1.0) g_tile_perm[k++] = c.second; }
+		else if (!strncmp(ord, "skytail:", 8)) { // the usual order, but the first K all-sky tiles of the sweep are handed out LAST: the paths that start last are one ray long
+			const size_t K = (size_t)atoi(ord + 8); size_t k = 0, moved = 0; std::vector<uint32_t> tail;
+			for (auto& c : cost) { if (c.first <= 1.0 && moved < K) { tail.push_back(c.second); moved++; } else g_tile_perm[k++] = c.second; }
+			for (auto t : tail) g_tile_perm[k++] = t;
+		}
 		else if (!strcmp(ord, "bottomup")) { for (size_t i = 0; i < cost.size(); ++i) g_tile_perm[i] = uint32_t(cost.size() - 1 - i); }
 		else if (!strcmp(ord, "skyfirst_terrain_lpt")) { size_t k = 0; for (auto& c : cost) if (c.first <= 1.0) g_tile_perm[k++] = c.second; std::vector<std::pair<double, uint32_t>> rest; for (auto& c : cost) if (c.first > 1.0) rest.push_back(c); std::stable_sort(rest.begin(), rest.end(), [](auto& a, auto& b) { return a.first > b.first; }); for (auto& c : rest) g_tile_perm[k++] = c.second; }
 		else g_tile_perm.clear();
