@@ -167,6 +167,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : (XCD ? BM_WAVES_PER_SIMD_BIG : BM_WA
 	// dispatched round-robin over the 8 XCDs, so blockIdx % 8 names the L2 -- so that the rays of neighbouring pixels, which read
 	// the same field rows, index words and bricks, are traced behind ONE L2 instead of all eight; a wave whose counter is used up
 	// helps the next one.  Otherwise: groups of four chunks dealt to the counters, every wave of a workgroup on its own counter.
+	// (blockIdx % 8 == XCD is the guide's "observed, for speed only" mapping: nothing here depends on it for correctness -- a wave that starts
+	// on another XCD's counter traces the same pixels with worse locality; tests render the same frame under both hand-outs.)
 	constexpr uint32_t kXcdTiles = 16u, kStChunks = kXcdTiles * kXcdTiles * 16u;
 	constexpr bool xcd_handout = XCD;
 	int my_counter = xcd_handout ? static_cast<int>(blockIdx.x % kCounters)
