@@ -38,7 +38,10 @@ for t in range(trials):
     plain = torch.zeros_like(acc)
     dbg = torch.zeros((H, W, 8), dtype=torch.int32, device="cuda:0")
     scene.render(cam, p, acc, debug=dbg)
-    scene.render(cam, p, plain)
+    p_ord = bm.FrameParams(W, H, spp=spp, sample_base=sb, max_bounces=mb, sun_position=sun, flags=bm.BM_FLAG_ORDERED)
+    scene.render(cam, p_ord, plain)                    # production instantiation, ordered sums: the instrumented frame's bits
+    prod = torch.zeros_like(acc)
+    scene.render(cam, p, prod)                         # production default: helper lanes, (chunk, sample) items for spp >= 2, float atomics
     pk = bm.FrameParams(W, H, spp=spp, sample_base=sb, max_bounces=mb, sun_position=sun, flags=bm.BM_FLAG_KSLOT)
     acc_k, plain_k, dbg_k = torch.zeros_like(acc), torch.zeros_like(acc), torch.zeros_like(dbg)
     scene.render(cam, pk, acc_k, debug=dbg_k)
@@ -47,6 +50,10 @@ for t in range(trials):
     oacc, odbg, _, _ = world.render(ocam, orc.make_frame(W, H, spp=spp, max_bounces=mb, sample_base=sb, sun=sun), threads=os.cpu_count() or 1)
     a, b, d = acc.cpu().numpy(), plain.cpu().numpy(), dbg.cpu().numpy().view(np.uint32)
     ok = np.array_equal(d, odbg) and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    c = prod.cpu().numpy()
+    both = np.isfinite(a) & np.isfinite(c)
+    ok = ok and np.array_equal(np.isfinite(a), np.isfinite(c)) and np.array_equal(np.where(both, c, 0)[..., 3], np.where(both, a, 0)[..., 3]) \
+        and np.allclose(np.where(both, c, 0)[..., :3], np.where(both, a, 0)[..., :3], rtol=2e-5, atol=1e-7)
     ok = ok and np.array_equal(dbg_k.cpu().numpy().view(np.uint32), d) and np.array_equal(acc_k.cpu().numpy().view(np.uint32), a.view(np.uint32)) \
         and np.array_equal(plain_k.cpu().numpy().view(np.uint32), a.view(np.uint32))
     fin = np.isfinite(oacc)
