@@ -425,13 +425,13 @@ __global__ __launch_bounds__(256, DBG ? 2 : (XCD ? BM_WAVES_PER_SIMD_BIG : BM_WA
 					const int n_pairs = min(__popcll(hand_m), __popcll(free_m));
 					const int hrank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(hand_m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(hand_m), 0u));
 					const int frank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(free_m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(free_m), 0u));
-					float* const slots = reinterpret_cast<float*>(lds_brick) + (threadIdx.x & ~63u); // word j of slot k at [j * 256 + k]: the wave's own columns
 					const bool gives = hand && hrank < n_pairs, takes = state == ST_IDLE && frank < n_pairs;
 					if (gives) {
-						slots[0 * 256 + hrank] = ro.x; slots[1 * 256 + hrank] = ro.y; slots[2 * 256 + hrank] = ro.z;
-						slots[3 * 256 + hrank] = rd.x; slots[4 * 256 + hrank] = rd.y; slots[5 * 256 + hrank] = rd.z;
-						slots[6 * 256 + hrank] = scolor.x; slots[7 * 256 + hrank] = scolor.y; slots[8 * 256 + hrank] = scolor.z;
-						slots[9 * 256 + hrank] = __uint_as_float(local_pixel);
+						const uint32_t k = static_cast<uint32_t>(hrank);
+						staging_word(lds_brick, k, 0) = ro.x; staging_word(lds_brick, k, 1) = ro.y; staging_word(lds_brick, k, 2) = ro.z;
+						staging_word(lds_brick, k, 3) = rd.x; staging_word(lds_brick, k, 4) = rd.y; staging_word(lds_brick, k, 5) = rd.z;
+						staging_word(lds_brick, k, 6) = scolor.x; staging_word(lds_brick, k, 7) = scolor.y; staging_word(lds_brick, k, 8) = scolor.z;
+						staging_word(lds_brick, k, 9) = __uint_as_float(local_pixel);
 						// the owner is done with this shadow ray: what connect would have done next happens now
 						if (terminated) { s++; pstate = P_GEN; need_setup = false; }
 						else { bounces++; ro = hitp; rd = bdir; r.n = pn; shadow = false; }
@@ -440,10 +440,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : (XCD ? BM_WAVES_PER_SIMD_BIG : BM_WA
 					__builtin_amdgcn_wave_barrier();
 					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 					if (takes) {
-						ro = mk(slots[0 * 256 + frank], slots[1 * 256 + frank], slots[2 * 256 + frank]);
-						rd = mk(slots[3 * 256 + frank], slots[4 * 256 + frank], slots[5 * 256 + frank]);
-						scolor = mk(slots[6 * 256 + frank], slots[7 * 256 + frank], slots[8 * 256 + frank]);
-						local_pixel = __float_as_uint(slots[9 * 256 + frank]);
+						const uint32_t k = static_cast<uint32_t>(frank);
+						ro = mk(staging_word(lds_brick, k, 0), staging_word(lds_brick, k, 1), staging_word(lds_brick, k, 2));
+						rd = mk(staging_word(lds_brick, k, 3), staging_word(lds_brick, k, 4), staging_word(lds_brick, k, 5));
+						scolor = mk(staging_word(lds_brick, k, 6), staging_word(lds_brick, k, 7), staging_word(lds_brick, k, 8));
+						local_pixel = __float_as_uint(staging_word(lds_brick, k, 9));
 						shadow = true;
 						pstate = P_HELPER;
 						need_setup = true;

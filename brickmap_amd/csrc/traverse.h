@@ -106,12 +106,35 @@ __device__ __forceinline__ void brick_dma_to_lds(unsigned long long* lds_brick, 
 #undef BM_DMA_WORD
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the loads write LDS: their data is there once they have returned
 }
+// measured alternative (-DBM_LDS_DMA=2): four 16-byte DMAs; chunk c (slices 2c, 2c + 1) of thread t at byte c * 4096 + t * 16 -- 12 fewer
+// memory instructions per candidate pass, two more vector instructions per voxel step (the slice address has two fields): within
+// noise of the default on every workload (profiles/r05_dma_variants.txt).  -DBM_LDS_DMA=0: bricks through registers (round 4).
+__device__ __forceinline__ void brick_dma4_to_lds(unsigned long long* lds_brick, const uint32_t* brick_words) {
+	const uint32_t wave_off = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>((threadIdx.x & ~63u) * 16u)));
+	char* const base = reinterpret_cast<char*>(lds_brick) + wave_off;
+#define BM_DMA_CHUNK(c) __builtin_amdgcn_global_load_lds((bm_global_cptr)brick_words, (bm_lds_ptr)(base + (c) * 4080), 16, (c) * 16, 0)
+	BM_DMA_CHUNK(0); BM_DMA_CHUNK(1); BM_DMA_CHUNK(2); BM_DMA_CHUNK(3);
+#undef BM_DMA_CHUNK
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Word j (0...15) of the 64-byte staging slot that belongs to lane k of the calling wave, as a float reference -- whatever the staging
+// layout, a wave may scribble over the slots of ITS OWN lanes when none of them is inside a brick walk (trace.hip uses them to hand
+// shadow rays from lane to lane in a shade pass); the slots of other waves may hold bricks that are being walked.
+__device__ __forceinline__ float& staging_word(unsigned long long* lds_brick, uint32_t k, uint32_t j) {
+	float* const f = reinterpret_cast<float*>(lds_brick);
+	const uint32_t t = (threadIdx.x & ~63u) + k;
+	if (BM_LDS_DMA == 2) return f[(j >> 2) * 1024u + t * 4u + (j & 3u)]; // chunk j / 4 of thread t
+	if (BM_LDS_DMA) return f[j * 256u + t];                               // word j of thread t
+	return f[((j >> 1) * 256u + t) * 2u + (j & 1u)];                      // half j & 1 of slice j / 2 of thread t
+}
 
 // OVERLAY (trace_k.hip): the brick is staged in four 16-byte chunks 4 KiB apart that belong to the calling thread alone
 // (`lds_brick` points at the first): slice z is the 64-bit half (z & 1) of chunk z >> 1.
 template <bool OVERLAY>
 __device__ __forceinline__ unsigned long long brick_slice(const unsigned long long* lds_brick, uint32_t z) {
 	if (OVERLAY) return lds_brick[(z >> 1) * 512u + (z & 1u)];
+	if (BM_LDS_DMA == 2) return lds_brick[(z >> 1) * 512u + threadIdx.x * 2u + (z & 1u)];
 	if (BM_LDS_DMA) {
 		const uint32_t* w = reinterpret_cast<const uint32_t*>(lds_brick) + z * 512u + threadIdx.x;
 		return static_cast<unsigned long long>(w[0]) | (static_cast<unsigned long long>(w[256]) << 32);
@@ -149,6 +172,8 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 		if (OVERLAY) {
 			uint4* q = reinterpret_cast<uint4*>(lds_brick);
 			q[0] = brick.q0; q[256] = brick.q1; q[512] = brick.q2; q[768] = brick.q3;
+		} else if (BM_LDS_DMA == 2) {
+			brick_dma4_to_lds(lds_brick, brick_words);
 		} else if (BM_LDS_DMA) {
 			brick_dma_to_lds(lds_brick, brick_words);
 		} else {
