@@ -45,10 +45,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # what bounds trace_paths on each workload (profiles/r0x_pmc_summary_<workload>.json, profiles/r03_fetch_calibration.txt)
 LIMITER = {
-    "config2": "VALU issue: the vector pipes are busy for >= 85 % of the launch with ~20 of 64 lanes active per instruction; the scene (93 MiB) stays in L2 / Infinity Cache",
-    "config3": "VALU issue, with 0.40 G single-sector reads reaching the fabric per launch (TCC hit 75 %; XCD-aware hand-out)",
-    "config5": "VALU issue (85 G wave instructions at ~19 of 64 lanes: the vector pipes are full); with the XCD-aware hand-out of big frames the fabric sees 30.5 G single-sector "
-               "(64 B) read requests/s = 0.63 of the 48 G/s it sustains for random sectors (0.92 before: a third less traffic bought 3 % of time)",
+    "config2": "VALU issue at the occupancy the registers allow (6 waves per SIMD): the vector pipes are busy for most of the launch with ~21 of 64 lanes active per "
+               "instruction (a wave's lanes are in different states; a pass costs the same with 15 or 64 of them); the scene (110 MiB) stays in L2 / Infinity Cache",
+    "config3": "VALU issue (7 waves per SIMD, ~23 of 64 lanes), with 0.4 G single-sector reads reaching the fabric per launch (XCD-aware hand-out)",
+    "config5": "VALU issue (79 G wave instructions at ~20 of 64 lanes) together with the fabric's request rate for single 64-byte sectors (every read of the walk is one "
+               "sector; the GPU sustains ~48 G such requests/s); occupancy (7 waves per SIMD) is what hides the walk's dependent loads",
 }
 PROFILE_ROUNDS = ("r05", "r04", "r03")  # profiles/<round>_pmc_summary_<workload>.json is where roofline.traffic comes from (newest first)
 
@@ -494,6 +495,9 @@ def main():
                          f"{world} x sample shards (every rank the full frame, {spp_rank} of the {spp_total} samples) + one RCCL sum-reduce to rank 0 after the last step"),
             "exchange": (None if not multi else ("C-ABI bm_gather_frame / bm_reduce_frame over RCCL (csrc/comm.hip)" if getattr(gatherer or reducer, "comm", None) is not None
                                                      else "torch.distributed gather / reduce")),
+            "frame_mode": ("ordered sums (BM_HELPERS=0: helper lanes off)" if os.environ.get("BM_HELPERS") == "0" else
+                           "production default: shadow rays on helper lanes, radiance added with float atomics (like the reference's connect, kernel.cu:341-343); "
+                           "multi-sample frames as (chunk, sample) work items; BM_FLAG_ORDERED frames -- what the parity suite compares bit for bit -- trace the same rays"),
             "camera": {"position": list(cam.position), "angles": [0.8, -0.5]},
             "world_build_s": round(build_s, 2),
         },
