@@ -78,6 +78,10 @@ struct FrameConstants {
 	int tiles_x, tiles_y; // 16x16-pixel tiles covering this shard's rows
 	int xcd_handout;      // 1: XCD-aware hand-out (trace.hip refill: 256x256-pixel super-tiles dealt to the eight XCDs' counters); big frames only
 	int refill_min;       // a wave takes new work items once this many of its lanes are idle (frame_constants(): by the length of an item)
+	// the hand-out's divisions by per-frame constants as multiply-high + shift (scene.cpp division_magic; magic == 0: the divisor is 1):
+	// samples per (chunk, sample) ticket group, tiles per row, rows per band, super-tiles per row.  Exact for dividends < 2^30.
+	uint32_t div_samples_magic, div_tiles_x_magic, div_band_magic, div_st_x_magic;
+	int div_samples_shift, div_tiles_x_shift, div_band_shift, div_st_x_shift;
 	int helpers;          // 1: shadow rays may be traced by idle lanes of the wave and added with float atomics (trace.hip HELP); 0: every pixel's events
 	                      // are accumulated in path order by the one lane that owns it (BM_FLAG_ORDERED, and every frame that writes hit records)
 };

@@ -47,6 +47,8 @@ float sun_intensity(float zenith_cos) {
 }
 } // namespace
 
+void division_magic(uint32_t d, uint32_t* magic, int* shift);
+
 int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_in, FrameConstants* fc, bool hit_records, bool kslot) {
 	if (!fp_in) { set_error("null argument"); return BM_EINVAL; }
 	// Which frames are ORDERED (every pixel's events accumulated in path order by one lane, one plain write-back: reproducible sums)?
@@ -141,6 +143,13 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_
 	fc->helpers = ordered ? 0 : 1;
 	static const int help_override = [] { const char* e = std::getenv("BM_HELPERS"); return e ? std::atoi(e) : -1; }();
 	if (help_override == 0 || (help_override == 1 && !ordered)) fc->helpers = help_override;
+	{ // divisions of the hand-out by per-frame constants (trace.hip refill): multiply-high + shift
+		auto set = [](uint32_t d, uint32_t* magic, int* shift) { if (d <= 1u) { *magic = 0u; *shift = 0; } else division_magic(d, magic, shift); };
+		set((fp->flags & BM_FLAG_SAMPLE_ITEMS) ? static_cast<uint32_t>(std::max(fp->spp, 1)) : 1u, &fc->div_samples_magic, &fc->div_samples_shift);
+		set(static_cast<uint32_t>(fc->tiles_x), &fc->div_tiles_x_magic, &fc->div_tiles_x_shift);
+		set(static_cast<uint32_t>(fc->band_rows), &fc->div_band_magic, &fc->div_band_shift);
+		set(static_cast<uint32_t>((fc->tiles_x + 15) / 16), &fc->div_st_x_magic, &fc->div_st_x_shift);
+	}
 	// The hand-out counts tickets in 32 bits (trace.hip: `my_tickets`, `base + want`).  The busiest counter owns a 1/8 share of the
 	// units -- groups of four chunks, or 256x256-pixel super-tiles of 4096 chunks -- times 16 tickets per chunk and, with (chunk,
 	// sample) items, per sample; every wave may overshoot a used-up counter once by up to 64.  Refuse what would wrap.
@@ -154,7 +163,7 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_
 		} else {
 			share = ((tiles * 4 + 7) / 8) * 4ll * per_chunk;
 		}
-		if (share >= (1ll << 32) - (1ll << 24)) {
+		if (share >= (1ll << 30) - (1ll << 24)) { // (2^30: the hand-out divides ticket numbers with 30-bit-exact multiply-high constants)
 			set_error("frame too large for the 32-bit ticket counters: tiles x samples per launch (lower spp per call, or render row-band shards)");
 			return BM_EINVAL;
 		}

@@ -34,6 +34,10 @@ namespace bm {
 //            whatever ray each of those lanes traces next                       (expensive, once per ray)
 // Scheduling changes only WHEN a lane's operations happen, never their operands, so results are
 // identical to the reference's per-ray functions run one ray at a time (the oracle).
+// floor(n / d) for a per-frame constant d whose multiply-high constants the host prepared (FrameConstants::div_*; magic == 0: d == 1);
+// n < 2^30.  Three instructions instead of the ~17 of a 32-bit division by a run-time value.
+__device__ __forceinline__ uint32_t div_const(uint32_t n, uint32_t magic, int shift) { return magic ? (__umulhi(n, magic) >> shift) : n; }
+
 enum : int { P_GEN = 0, P_EXT_DONE = 1, P_SHD_DONE = 2, P_BOUNCE = 3, P_HELPER = 6 };
 enum : int { ST_IDLE = 4, ST_CONN = 5 };
 
@@ -222,7 +226,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : (XCD ? BM_WAVES_PER_SIMD_BIG : BM_WA
 			const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
 			if (state == ST_IDLE && rank < want * BM_ITEM_LANES) {
 				const uint32_t item = base + static_cast<uint32_t>(rank / BM_ITEM_LANES);
-				const uint32_t ticket = item / items_per_chunk, item_sub = item - ticket * items_per_chunk;
+				// items_per_chunk = samples x kParts: divide by the power of two first, then by the samples (a prepared constant)
+				static_assert((kParts & (kParts - 1u)) == 0u, "kParts is a power of two");
+				const uint32_t ticket = div_const(item / kParts, fc.div_samples_magic, fc.div_samples_shift), item_sub = item - ticket * items_per_chunk;
 				const uint32_t item_sample = item_sub / kParts, part = item_sub % kParts; // (kParts == 1: part 0)
 				uint32_t k;
 				int tile_x, tile_y;
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : (XCD ? BM_WAVES_PER_SIMD_BIG : BM_WA
 					const uint32_t st = (ticket / kStChunks) * kCounters + counter_now, in_st = ticket % kStChunks;
 					const uint32_t tw = in_st >> 4;
 					k = in_st & 15u;
-					const uint32_t st_row = st / st_x;
+					const uint32_t st_row = div_const(st, fc.div_st_x_magic, fc.div_st_x_shift);
 					tile_x = static_cast<int>((st - st_row * st_x) * kXcdTiles + tw % kXcdTiles);
 					tile_y = static_cast<int>(st_row * kXcdTiles + tw / kXcdTiles);
 					in_frame = tile_x < fc.tiles_x && tile_y < fc.tiles_y;
@@ -239,8 +245,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : (XCD ? BM_WAVES_PER_SIMD_BIG : BM_WA
 					const uint32_t chunk = ((ticket >> 2) * kCounters + counter_now) * 4u + (ticket & 3u);
 					const uint32_t tile = chunk >> 4;
 					k = chunk & 15u;
-					tile_x = static_cast<int>(tile % static_cast<uint32_t>(fc.tiles_x));
-					tile_y = static_cast<int>(tile / static_cast<uint32_t>(fc.tiles_x));
+					tile_y = static_cast<int>(div_const(tile, fc.div_tiles_x_magic, fc.div_tiles_x_shift));
+					tile_x = static_cast<int>(tile - static_cast<uint32_t>(tile_y) * static_cast<uint32_t>(fc.tiles_x));
 					in_frame = chunk < total_chunks;
 				}
 				if (item < my_tickets && in_frame) {
@@ -248,7 +254,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : (XCD ? BM_WAVES_PER_SIMD_BIG : BM_WA
 					const uint32_t q = part * BM_ITEM_LANES + (static_cast<uint32_t>(rank) % BM_ITEM_LANES); // pixel of the 4x4 chunk
 					const int x = tile_x * 16 + cx * 4 + static_cast<int>(q & 3u);
 					const int ly = tile_y * 16 + cy * 4 + static_cast<int>(q >> 2); // row inside this shard's packed buffer
-					const int y = ((ly / fc.band_rows) * fc.shard_count + fc.shard_rank) * fc.band_rows + ly % fc.band_rows;
+					const int band = static_cast<int>(div_const(static_cast<uint32_t>(ly), fc.div_band_magic, fc.div_band_shift)); // ly / band_rows
+					const int y = (band * fc.shard_count + fc.shard_rank) * fc.band_rows + (ly - band * fc.band_rows);
 					if (x < fc.width && ly < fc.local_rows && y < fc.height) {
 						p = static_cast<uint32_t>(y) * W + static_cast<uint32_t>(x);
 						local_pixel = static_cast<uint32_t>(ly) * W + static_cast<uint32_t>(x);
