@@ -223,13 +223,19 @@ def main():
     if by_rows:
         gatherer = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev, force_collective=True, side_stream=gather_side)
 
+    exchange_error = None
     if multi and not share_gpu and os.environ.get("BM_DIST_TORCH", "0") != "1":
         # the exchange of an RCCL group is the C-ABI's (bm_comm_create + bm_comm_selftest ran inside the constructor above, on every
-        # rank): a run that silently fell back to torch.distributed would not be the product's path -- fail loudly, with RCCL's words
+        # rank).  If it could not be made, say so LOUDLY, with RCCL's words -- on stderr and in the line (`ranks.exchange_error`) -- and
+        # go on with torch.distributed's gather over the same RCCL, so that a multi-GPU run still yields its number;
+        # BM_BENCH_STRICT=1 makes it the run's failure instead.
         ex = gatherer if gatherer is not None else reducer
         if getattr(ex, "comm", None) is None:
-            raise SystemExit(f"bench.py rank {rank}/{world}: the C-ABI RCCL exchange failed its start-up self-test (bm_comm_create / bm_comm_selftest): "
-                             f"{bm.dist.last_comm_error or 'no error text'}")
+            exchange_error = (f"rank {rank}/{world}: the C-ABI RCCL exchange failed its start-up self-test (bm_comm_create / bm_comm_selftest): "
+                              f"{bm.dist.last_comm_error or 'no error text'}")
+            print("bench.py: " + exchange_error + " -- falling back to torch.distributed's exchange", file=sys.stderr, flush=True)
+            if os.environ.get("BM_BENCH_STRICT") == "1":
+                raise SystemExit("bench.py " + exchange_error)
 
     gathered = {}  # --verify: the last gathered frame of every accumulation buffer (rank 0)
 
@@ -302,6 +308,7 @@ def main():
         every = [None] * world
         dist.all_gather_object(every, mine)
         ranks_info = {"process_group_world": dist.get_world_size(), "process_group_backend": dist.get_backend(),
+                      "exchange_error": exchange_error,  # None: the C-ABI exchange passed its self-test on this rank (a failure on any rank makes all fall back)
                       "communicator_world": comm_world,  # bm_comm_info of the C-ABI communicator the frames travelled through (None: torch.distributed's exchange)
                       "ms_per_step": [e["ms_per_step"] for e in every], "kernel_ms_avg": [e["kernel_ms_avg"] for e in every],
                       "devices": [f'{e["device"]} #{e["device_index"]}' + (f' {e["pci_bus_id"]}' if e["pci_bus_id"] is not None else "") for e in every]}
