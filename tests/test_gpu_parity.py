@@ -356,6 +356,49 @@ def test_streaming_first_frame_and_steady_state(bm, orc, torch_cuda):
     scene.close()
 
 
+def test_helper_lanes_request_the_same_bricks(bm, orc, torch_cuda):
+    """Streaming with production frames: shadow rays traced by helper lanes raise brick requests like any other ray (voxel.cuh:228-245).
+    From empty residency, production frames (helper lanes, 2 spp as (chunk, sample) items) and ordered frames request the same SET of
+    bricks frame by frame -- the counts serviced per frame are equal, the resident sets end up identical, and the first frame's requests
+    are the oracle's -- although the ORDER in which a frame's lanes reach the ring differs."""
+    G, W, H = 256, 112, 80
+    torch = torch_cuda
+    cam, ocam = cameras(bm, orc, G)
+    w = orc.World(G, G)
+    w.set_queue_cap(1 << 16)
+    w.reset_device(False)
+    _, _, ocnt, _ = w.render(ocam, orc.make_frame(W, H, spp=2, max_bounces=3))
+    scenes, counts = [], []
+    for flags in (0, bm.BM_FLAG_ORDERED):
+        sc = bm.Scene(G, G, device=0)
+        sc.set_queue_capacity(1 << 16)
+        sc.generate()
+        acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+        per_frame = []
+        for _ in range(64):
+            sc.render(cam, bm.FrameParams(W, H, spp=2, max_bounces=3, flags=flags), acc)
+            n = sc.process_load_queue()
+            per_frame.append(n)
+            if n == 0:
+                break
+        else:
+            pytest.fail("no streaming steady state")
+        scenes.append(sc)
+        counts.append(per_frame)
+    assert counts[0] == counts[1] and counts[0][0] == ocnt["requests"] > 0
+    a, b = scenes
+    assert a.info()["resident_bricks"] == b.info()["resident_bricks"] == sum(counts[0])
+    for sci in range(w.nsc):
+        ia, ib = a.device_indices(sci), b.device_indices(sci)
+        # the same bricks are resident (loaded bit), whatever slot the request order gave them
+        assert np.array_equal(ia >> 31, ib >> 31) and np.array_equal(ia == 0, ib == 0)
+    # ... and the steady-state frames agree: ordered bit for bit with each other, the production frame to summation order
+    pa, _ = gpu_render(bm, torch, a, cam, bm.FrameParams(W, H, spp=2, max_bounces=3), want_dbg=False)
+    pb, _ = gpu_render(bm, torch, b, cam, bm.FrameParams(W, H, spp=2, max_bounces=3), want_dbg=False)
+    assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32))
+    a.close(); b.close()
+
+
 def test_request_ring_overflow(bm, orc, torch_cuda):
     """A frame that wants more bricks than the ring holds gets exactly `capacity` serviced; the losers'
     request bits are cleared again (voxel.cuh:234-240) so that they can ask again next frame."""
