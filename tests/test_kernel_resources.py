@@ -12,9 +12,11 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "brickmap_amd", "csrc")
-# trace_paths<instrumented = false, XCD-aware hand-out, helper lanes>: the four production instantiations (the default of production
-# frames is <false, *, true>; BM_FLAG_ORDERED frames run <false, *, false>)
-KERNELS = ("_ZN2bm11trace_pathsILb0ELb0ELb1E", "_ZN2bm11trace_pathsILb0ELb1ELb1E", "_ZN2bm11trace_pathsILb0ELb0ELb0E", "_ZN2bm11trace_pathsILb0ELb1ELb0E")
+# trace_paths<instrumented = false, XCD-aware hand-out, helper lanes, DEEP (7 waves per SIMD)>: the production instantiations (the default
+# of production frames is <false, *, true, *>; BM_FLAG_ORDERED frames run <false, *, false, *>; big frames are always XCD + DEEP,
+# launches with several samples per pixel DEEP)
+KERNELS = ("_ZN2bm11trace_pathsILb0ELb0ELb1ELb0E", "_ZN2bm11trace_pathsILb0ELb1ELb1ELb1E", "_ZN2bm11trace_pathsILb0ELb0ELb0ELb0E", "_ZN2bm11trace_pathsILb0ELb1ELb0ELb1E",
+           "_ZN2bm11trace_pathsILb0ELb0ELb1ELb1E", "_ZN2bm11trace_pathsILb0ELb0ELb0ELb1E")
 
 
 import pytest
@@ -30,7 +32,7 @@ def test_production_kernel_keeps_its_register_budget_and_its_shape(KERNEL):
     def field(name):
         return int(re.search(name + r": (\d+)", block).group(1))
 
-    big = "ILb0ELb1E" in KERNEL  # the XCD instantiation big frames take: 7 waves per SIMD, the others 6 (trace.hip BM_WAVES_PER_SIMD*)
+    big = KERNEL.endswith("Lb1E")  # DEEP: 7 waves per SIMD, the others 6 (trace.hip BM_WAVES_PER_SIMD*)
     if big:
         assert field("VGPRs") <= 72 and field(r"Occupancy \[waves/SIMD\]") == 7
         assert field("VGPRs Spill") <= 6 and field(r"ScratchSize \[bytes/lane\]") <= 32, "7 waves were measured with 5 spilled registers; more was not"
