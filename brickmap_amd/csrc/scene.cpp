@@ -57,7 +57,7 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_
 	// (trace.hip HELP) and, when a pixel has several samples, with (4x4 chunk, sample) work items: shorter items, a shorter tail,
 	// coherent neighbouring samples (1080p at 4 spp 4.0 -> 3.4 ms, config 3 -4 %).  BM_HELPERS=0 / 1 overrides helper lanes (A/B runs).
 	bm_frame_params promoted = *fp_in;
-	const bool ordered = (promoted.flags & (BM_FLAG_ORDERED | BM_FLAG_PRIMARY_ONLY)) != 0 || hit_records || kslot;
+	const bool ordered = (promoted.flags & (BM_FLAG_ORDERED | BM_FLAG_PRIMARY_ONLY)) != 0 || hit_records || kslot || promoted.spp < 1; // (spp = 0: nothing to trace)
 	if (!ordered && promoted.spp >= 2) promoted.flags |= BM_FLAG_SAMPLE_ITEMS;
 	const bm_frame_params* const fp = &promoted;
 	if (!cam || !fp || !fc) { set_error("null argument"); return BM_EINVAL; }

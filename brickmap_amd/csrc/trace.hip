@@ -163,7 +163,18 @@ __global__ __launch_bounds__(256, DBG ? 2 : (DEEP ? BM_WAVES_PER_SIMD_BIG : BM_W
 	f3 bdir = mk(0.f, 0.f, 0.f);   // next bounce direction, drawn in shade, used once the shadow ray is done
 	// the pixel's accumulator (state.h:22): read when the lane takes the pixel, updated in path order in registers, written
 	// back once when the pixel is finished -- a read-modify-write in memory per event stalls the wave for a load round trip
+	// (HELP: no lane-private accumulator at all -- every event goes to the pixel with float atomics when it happens, like the reference's
+	// shade / connect do (kernel.cu:301,319-322,341-343): four registers less per lane, i.e. fewer spills at seven waves per SIMD --
+	// config 3 -1.4 %, config 5 -1.7 %, profiles/r05_event_atomics.txt)
 	float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+	auto add_rgb = [&](f3 c) {
+		if (HELP) { float* a = reinterpret_cast<float*>(accum + local_pixel); unsafeAtomicAdd(a + 0, c.x); unsafeAtomicAdd(a + 1, c.y); unsafeAtomicAdd(a + 2, c.z); }
+		else { acc.x += c.x; acc.y += c.y; acc.z += c.z; }
+	};
+	auto add_terminated = [&]() {
+		if (HELP) unsafeAtomicAdd(reinterpret_cast<float*>(accum + local_pixel) + 3, 1.f);
+		else acc.w += 1.f;
+	};
 
 	bool work_left = true;
 	constexpr uint32_t kCounters = BM_WORK_COUNTERS, kCounterStride = 32; // one 128-byte line per counter
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : (DEEP ? BM_WAVES_PER_SIMD_BIG : BM_W
 						s_end = sample_items ? s + 1 : fc.spp;
 						pstate = P_GEN;
 						state = ST_NEED;
-						acc = atomic_acc ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[local_pixel];
+						if (!HELP) acc = atomic_acc ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[local_pixel];
 						if (DBG) {
 							d0 = 0; d1 = 0; d2 = 0xFFFFFFFFu; d3 = 0; hseg = 2166136261u; hsh = 2166136261u; next = 0; nsh = 0;
 							loads0 = tally.index_loads;
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : (DEEP ? BM_WAVES_PER_SIMD_BIG : BM_W
 						state = ST_IDLE; // (pstate stays P_HELPER: none of the blocks below applies)
 					} else {
 						if (!occluded) {
-							acc.x += scolor.x; acc.y += scolor.y; acc.z += scolor.z;
+							add_rgb(scolor);
 						}
 						state = ST_NEED;
 						if (terminated) {
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : (DEEP ? BM_WAVES_PER_SIMD_BIG : BM_W
 						cast = sunLight > 0.f;
 						terminated = !(bounces < fc.max_bounces);
 						if (terminated) {
-							acc.w += 1.f; // kernel.cu:301
+							add_terminated(); // kernel.cu:301
 						} else {
 							// kernel.cu:281-299: cosine-weighted bounce, drawn right after the cone sample as in shade();
 							// the direction is kept in `bdir` until the shadow ray (if any) has been traced.
@@ -418,8 +429,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : (DEEP ? BM_WAVES_PER_SIMD_BIG : BM_W
 						}
 					}
 					if (!is_hit || primary_only) { // the path ends here
-						acc.x += miss_color.x; acc.y += miss_color.y; acc.z += miss_color.z; // (0,0,0) for a primary-only hit
-						acc.w += 1.f;
+						if (!(is_hit && primary_only)) add_rgb(miss_color); // (nothing to add for a primary-only hit)
+						add_terminated();
 						s++;
 						pstate = P_GEN;
 					}
@@ -466,7 +477,9 @@ __global__ __launch_bounds__(256, DBG ? 2 : (DEEP ? BM_WAVES_PER_SIMD_BIG : BM_W
 				if (pstate == P_GEN) {
 					if (s >= s_end) {
 						// item finished: write the accumulator back (or add this sample's share) and wait for the next one
-						if (atomic_acc) {
+						if (HELP) {
+							// (every event has been added already)
+						} else if (atomic_acc) {
 							float* a = reinterpret_cast<float*>(accum + local_pixel);
 							unsafeAtomicAdd(a + 0, acc.x); unsafeAtomicAdd(a + 1, acc.y); unsafeAtomicAdd(a + 2, acc.z); unsafeAtomicAdd(a + 3, acc.w);
 						} else {
