@@ -524,11 +524,11 @@ def main():
             "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
             **counter_figures(args.workload, avg_kernel_s),
             # (the plain instantiation; big frames -- 32000 tiles and more, scene.cpp frame_constants -- take the XCD-aware hand-out)
-            # (the plain instantiation <instrumented = false, XCD-aware hand-out, helper lanes, 7 waves per SIMD instead of 6>: big frames -- 32000 tiles and more, scene.cpp
+            # (the plain instantiation <instrumented = false, XCD-aware hand-out, helper lanes>: big frames -- 32000 tiles and more, scene.cpp
             # frame_constants -- take the XCD-aware hand-out; production frames run with helper lanes unless BM_FLAG_ORDERED / BM_HELPERS=0)
-            "kernel": (lambda xcd: "bm::trace_paths<false, %s, %s, %s>" % (
-                "true" if xcd else "false", "false" if os.environ.get("BM_HELPERS") == "0" else "true", "true" if (xcd or state.local_rows * W * spp_rank >= 3000000) else "false"))(
-                (((W + 15) // 16) * ((state.local_rows + 15) // 16) >= 32000 and os.environ.get("BM_XCD_HANDOUT") != "0") or os.environ.get("BM_XCD_HANDOUT") == "1"),
+            "kernel": "bm::trace_paths<false, %s, %s>" % (
+                "true" if (((W + 15) // 16) * ((state.local_rows + 15) // 16) >= 32000 and os.environ.get("BM_XCD_HANDOUT") != "0") or os.environ.get("BM_XCD_HANDOUT") == "1" else "false",
+                "false" if os.environ.get("BM_HELPERS") == "0" else "true"),
             "kernel_ms_avg": round(float(np.mean(kernel_ms)), 4),
             "algorithmic_bytes_per_launch": alg_bytes / args.steps,
             "bytes_per_actual_ray": round(alg_bytes / max(actual_rays, 1), 1),

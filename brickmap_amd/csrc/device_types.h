@@ -82,7 +82,6 @@ struct FrameConstants {
 	// samples per (chunk, sample) ticket group, tiles per row, rows per band, super-tiles per row.  Exact for dividends < 2^30.
 	uint32_t div_samples_magic, div_tiles_x_magic, div_band_magic, div_st_x_magic;
 	int div_samples_shift, div_tiles_x_shift, div_band_shift, div_st_x_shift;
-	int deep;             // 1: the instantiation bounded at 7 waves per SIMD (big frames, launches with several samples per pixel; trace.hip DEEP)
 	int helpers;          // 1: shadow rays may be traced by idle lanes of the wave and added with float atomics (trace.hip HELP); 0: every pixel's events
 	                      // are accumulated in path order by the one lane that owns it (BM_FLAG_ORDERED, and every frame that writes hit records)
 };

@@ -6,7 +6,7 @@
 
 namespace bm {
 constexpr size_t kWorkCounterBytes = 64 * 32 * sizeof(uint32_t); // up to 64 chunk counters, one 128-byte line each
-int trace_blocks_per_cu(bool instrumented, bool xcd_handout, bool helpers, bool deep); // resident workgroups per CU of that instantiation
+int trace_blocks_per_cu(bool instrumented, bool xcd_handout, bool helpers); // resident workgroups per CU of that instantiation
 // blocks_per_cu_cap: 0 = as many workgroups per CU as the instantiation keeps resident; > 0 = at most that many (tuning runs)
 void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameConstants* fc_dev, float* accum, uint32_t* dbg, DeviceCounters* counters,
 				  uint32_t* work_counter, bool instrumented, int compute_units, int blocks_per_cu_cap, hipStream_t stream);

@@ -137,10 +137,6 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_
 	fc->xcd_handout = (static_cast<long long>(fc->tiles_x) * fc->tiles_y >= 32000) ? 1 : 0;
 	static const int xcd_override = [] { const char* e = std::getenv("BM_XCD_HANDOUT"); return e ? std::atoi(e) : -1; }(); // tuning runs / tests
 	if (xcd_override == 0 || xcd_override == 1) fc->xcd_handout = xcd_override;
-	// seven waves per SIMD instead of six (trace.hip DEEP) where the launch is long against its end: big frames, and launches of
-	// >= 3 M paths -- ~7 per resident lane -- (1080p at 4 spp -2 %, the 8-spp job -2.3 %); a 2 M-path launch -- the 1-spp 1080p frame, a 1/8
-	// shard of the 8-spp job -- is dominated by its last paths' latency and loses 1-3 % to the seventh wave's spilled registers
-	fc->deep = (fc->xcd_handout || static_cast<long long>(fc->local_rows) * fc->width * std::max(fp->spp, 1) >= 3000000ll) ? 1 : 0;
 	static const int refill_override = [] { const char* e = std::getenv("BM_REFILL_MIN"); return e ? std::atoi(e) : 0; }(); // tuning runs
 	if (refill_override >= 1 && refill_override <= 64) fc->refill_min = refill_override;
 	// shadow rays on helper lanes (trace.hip HELP): every frame that is not ordered (above)

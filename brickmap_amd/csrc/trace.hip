@@ -43,14 +43,13 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 
 // Resident waves per SIMD of the production instantiations (the register budget follows: 512 / waves, in steps of 8).  Round 5:
 // with the brick staged straight into LDS (traverse.h brick_dma_to_lds) no lane holds a brick's 16 registers any more -- 84 VGPRs
-// instead of 95 -- and SIX waves fit without a spill (79 VGPRs): config 2 1.066 -> 1.020 ms, config 3 23.4 -> 21.8, config 5
-// 113.7 -> 105.1.  SEVEN waves (72 VGPRs, 5 of them spilled to scratch) change nothing on the cache-resident config 2 and give the
-// big worlds another 2 % (21.4 / 102.9 ms): the instantiation that big frames take anyway (XCD) runs at 7 (profiles/r05_occupancy.txt).
+// instead of 95 -- and six waves fit without a spill: config 2 1.066 -> 1.020 ms, config 3 23.4 -> 21.8, config 5 113.7 -> 105.1.
+// Seven waves (72 VGPRs) first cost five spilled registers and paid on the big workloads only; once helper-lane frames kept no
+// accumulator (below) the two values still spilled are constants of a cold branch (rays that start outside the world), and seven
+// waves pay everywhere: config 2 1.023 -> 1.009 ms, 1080p at 4 spp -2 %, configs 3 / 5 -2 % (profiles/r05_occupancy.txt,
+// r05_deep.txt).  Eight waves (64 VGPRs, 13+ spilled) lose 8-16 %.
 #ifndef BM_WAVES_PER_SIMD
-#define BM_WAVES_PER_SIMD 6
-#endif
-#ifndef BM_WAVES_PER_SIMD_BIG
-#define BM_WAVES_PER_SIMD_BIG 7
+#define BM_WAVES_PER_SIMD 7
 #endif
 #ifndef BM_ITEM_LANES
 // pixels handed out per ticket: 1 = a refill fills EVERY idle lane (consecutive tickets still walk through a 4x4 chunk row by row).
@@ -114,12 +113,9 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 // (kernel.cu:341-343).  The rays traced are the same rays; what changes is who walks them: idle lanes do useful work without a
 // refill, and a path's latency -- which is what the end of a frame waits for -- is its extend rays' alone.  Pixels are therefore
 // written back with atomics as well (the accumulator starts at zero in the lane), so radiance is equal up to summation order.
-// DEEP: bounded at BM_WAVES_PER_SIMD_BIG resident waves per SIMD instead of BM_WAVES_PER_SIMD (FrameConstants::deep: big frames and
-// launches of >= 3 M paths, where the seventh wave pays: 1080p at 4 spp -2 %, configs 3 and 5 -2 %; a 2 M-path launch -- the 1-spp 1080p
-// frame, a 1/8 shard of the multi-GPU job -- loses 1-3 % to the spilled registers and stays at six; profiles/r05_deep.txt)
-template <bool DBG, bool XCD = false, bool HELP = false, bool DEEP = false>
+template <bool DBG, bool XCD = false, bool HELP = false>
 // (the instrumented variant carries hit records and counters: it gets the registers instead of the occupancy)
-__global__ __launch_bounds__(256, DBG ? 2 : (DEEP ? BM_WAVES_PER_SIMD_BIG : BM_WAVES_PER_SIMD)) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, float4* __restrict__ accum,
+__global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, float4* __restrict__ accum,
 												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters,
 												  uint32_t* __restrict__ work_counter) {
 	// the per-frame constants live in device memory (not in the kernel-argument registers): they are read with scalar
@@ -700,23 +696,18 @@ __global__ void debug_sky_kernel(const FrameConstants fc, int n, const float* __
 
 // ---- host-callable launchers (kernels.h)
 // resident 256-thread workgroups per compute unit of one instantiation (asked once per instantiation)
-template <bool DBG, bool XCD, bool HELP, bool DEEP>
+template <bool DBG, bool XCD, bool HELP>
 static int occupancy_of() {
 	static const int cached = [] {
 		int n = 0;
-		const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<DBG, XCD, HELP, DEEP>, 256, 0);
+		const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<DBG, XCD, HELP>, 256, 0);
 		return e == hipSuccess && n > 0 ? n : 1;
 	}();
 	return cached;
 }
-// (instantiated: the instrumented kernels without DEEP -- their launch bound is 2 either way -- and the production ones with DEEP
-// whenever XCD is set: big frames always run deep)
-int trace_blocks_per_cu(bool instrumented, bool xcd, bool help, bool deep) {
-	if (instrumented) return xcd ? (help ? occupancy_of<true, true, true, false>() : occupancy_of<true, true, false, false>())
-								 : (help ? occupancy_of<true, false, true, false>() : occupancy_of<true, false, false, false>());
-	if (xcd) return help ? occupancy_of<false, true, true, true>() : occupancy_of<false, true, false, true>();
-	if (deep) return help ? occupancy_of<false, false, true, true>() : occupancy_of<false, false, false, true>();
-	return help ? occupancy_of<false, false, true, false>() : occupancy_of<false, false, false, false>();
+int trace_blocks_per_cu(bool instrumented, bool xcd, bool help) {
+	if (instrumented) return xcd ? (help ? occupancy_of<true, true, true>() : occupancy_of<true, true, false>()) : (help ? occupancy_of<true, false, true>() : occupancy_of<true, false, false>());
+	return xcd ? (help ? occupancy_of<false, true, true>() : occupancy_of<false, true, false>()) : (help ? occupancy_of<false, false, true>() : occupancy_of<false, false, false>());
 }
 
 // Persistent launch: exactly as many 256-thread workgroups as the device keeps resident (compute_units x
@@ -726,8 +717,7 @@ void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameCo
 	const long long chunks = static_cast<long long>(fc.tiles_x) * fc.tiles_y * 16;
 	if (chunks <= 0) return;
 	const bool xcd = fc.xcd_handout != 0;
-	const bool deep = xcd || fc.deep != 0;
-	int per_cu = trace_blocks_per_cu(instrumented, xcd, fc.helpers != 0, deep); // what THIS instantiation keeps resident
+	int per_cu = trace_blocks_per_cu(instrumented, xcd, fc.helpers != 0); // what THIS instantiation keeps resident
 	if (blocks_per_cu_cap > 0 && per_cu > blocks_per_cu_cap) per_cu = blocks_per_cu_cap;
 	const long long resident_blocks = static_cast<long long>(compute_units) * per_cu;
 	long long blocks = (chunks + 15) / 16; // never more workgroups than 64-pixel groups
@@ -740,16 +730,13 @@ void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameCo
 	DeviceCounters* const plain_counters = nullptr;
 #endif
 	const bool help = fc.helpers != 0;
-#define BM_LAUNCH_TRACE(D, X, H, P, DBGBUF, CNT) hipLaunchKernelGGL((trace_paths<D, X, H, P>), grid, block, 0, stream, sc, fc_dev, acc4, DBGBUF, CNT, work_counter)
+#define BM_LAUNCH_TRACE(D, X, H, DBGBUF, CNT) hipLaunchKernelGGL((trace_paths<D, X, H>), grid, block, 0, stream, sc, fc_dev, acc4, DBGBUF, CNT, work_counter)
 	if (instrumented) {
-		if (xcd) { if (help) BM_LAUNCH_TRACE(true, true, true, false, dbg, counters); else BM_LAUNCH_TRACE(true, true, false, false, dbg, counters); }
-		else { if (help) BM_LAUNCH_TRACE(true, false, true, false, dbg, counters); else BM_LAUNCH_TRACE(true, false, false, false, dbg, counters); }
-	} else if (xcd) {
-		if (help) BM_LAUNCH_TRACE(false, true, true, true, nullptr, plain_counters); else BM_LAUNCH_TRACE(false, true, false, true, nullptr, plain_counters);
-	} else if (deep) {
-		if (help) BM_LAUNCH_TRACE(false, false, true, true, nullptr, plain_counters); else BM_LAUNCH_TRACE(false, false, false, true, nullptr, plain_counters);
+		if (xcd) { if (help) BM_LAUNCH_TRACE(true, true, true, dbg, counters); else BM_LAUNCH_TRACE(true, true, false, dbg, counters); }
+		else { if (help) BM_LAUNCH_TRACE(true, false, true, dbg, counters); else BM_LAUNCH_TRACE(true, false, false, dbg, counters); }
 	} else {
-		if (help) BM_LAUNCH_TRACE(false, false, true, false, nullptr, plain_counters); else BM_LAUNCH_TRACE(false, false, false, false, nullptr, plain_counters);
+		if (xcd) { if (help) BM_LAUNCH_TRACE(false, true, true, nullptr, plain_counters); else BM_LAUNCH_TRACE(false, true, false, nullptr, plain_counters); }
+		else { if (help) BM_LAUNCH_TRACE(false, false, true, nullptr, plain_counters); else BM_LAUNCH_TRACE(false, false, false, nullptr, plain_counters); }
 	}
 #undef BM_LAUNCH_TRACE
 }

@@ -128,7 +128,7 @@ def test_bench_big_multi_gpu_workloads_dry_run_with_one_rank(workload):
     assert out["n_gpus"] == 1 and out["value"] > 0
     assert out["config"]["spp_per_step"] == (16 if workload == "config4" else 32)
     assert out["ranks"]["communicator_world"] == 1 and out["ranks"]["process_group_backend"] == "nccl" and "C-ABI" in out["config"]["exchange"]
-    assert "trace_paths<false, true, true, true>" in out["roofline"]["kernel"]  # the XCD-aware hand-out of big frames, helper lanes
+    assert "trace_paths<false, true, true>" in out["roofline"]["kernel"]  # the XCD-aware hand-out of big frames, helper lanes
 
 
 def test_multi_gpu_step_loop_overlaps_frames_on_two_streams():

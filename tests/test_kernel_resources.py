@@ -1,6 +1,6 @@
 """Guard rails for the production kernel's compiled shape (CPU only: hipcc cross-compiles gfx950 without a GPU).
 
-bm::trace_paths<false, ...> is bound by vector-instruction issue at 6 waves per SIMD (7 for big frames).  Two things
+bm::trace_paths<false, ...> is bound by vector-instruction issue at 7 waves per SIMD.  Two things
 silently cost 5-10 % and have both happened: a register budget one step too high (one wave per SIMD less, or spills), and the backend
 linearising the scheduler loop's scalar branches again, which keeps every lane's state in two register sets and copies
 one onto the other around every pass (a few hundred extra v_mov; a small change to the loop's control flow is enough).
@@ -12,11 +12,9 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "brickmap_amd", "csrc")
-# trace_paths<instrumented = false, XCD-aware hand-out, helper lanes, DEEP (7 waves per SIMD)>: the production instantiations (the default
-# of production frames is <false, *, true, *>; BM_FLAG_ORDERED frames run <false, *, false, *>; big frames are always XCD + DEEP,
-# launches with several samples per pixel DEEP)
-KERNELS = ("_ZN2bm11trace_pathsILb0ELb0ELb1ELb0E", "_ZN2bm11trace_pathsILb0ELb1ELb1ELb1E", "_ZN2bm11trace_pathsILb0ELb0ELb0ELb0E", "_ZN2bm11trace_pathsILb0ELb1ELb0ELb1E",
-           "_ZN2bm11trace_pathsILb0ELb0ELb1ELb1E", "_ZN2bm11trace_pathsILb0ELb0ELb0ELb1E")
+# trace_paths<instrumented = false, XCD-aware hand-out, helper lanes>: the four production instantiations (the default of production
+# frames is <false, *, true>; BM_FLAG_ORDERED frames run <false, *, false>)
+KERNELS = ("_ZN2bm11trace_pathsILb0ELb0ELb1E", "_ZN2bm11trace_pathsILb0ELb1ELb1E", "_ZN2bm11trace_pathsILb0ELb0ELb0E", "_ZN2bm11trace_pathsILb0ELb1ELb0E")
 
 
 import pytest
@@ -32,14 +30,11 @@ def test_production_kernel_keeps_its_register_budget_and_its_shape(KERNEL):
     def field(name):
         return int(re.search(name + r": (\d+)", block).group(1))
 
-    big = KERNEL.endswith("Lb1E")  # DEEP: 7 waves per SIMD, the others 6 (trace.hip BM_WAVES_PER_SIMD*)
-    if big:
-        assert field("VGPRs") <= 72 and field(r"Occupancy \[waves/SIMD\]") == 7
-        assert field("VGPRs Spill") <= 6 and field(r"ScratchSize \[bytes/lane\]") <= 32, "7 waves were measured with 5 spilled registers; more was not"
-    else:
-        assert field("VGPRs") <= 80, "more than 80 VGPRs: 5 waves per SIMD instead of 6"
-        assert field("VGPRs Spill") == 0 and field(r"ScratchSize \[bytes/lane\]") == 0
-        assert field(r"Occupancy \[waves/SIMD\]") == 6
+    helpers = KERNEL.endswith("Lb1E")  # the default of production frames; the ordered instantiations keep an accumulator (4 more registers)
+    assert field("VGPRs") <= 72 and field(r"Occupancy \[waves/SIMD\]") == 7, "more than 72 VGPRs: 6 waves per SIMD instead of 7"
+    # what is spilled at seven waves are two loop-invariant constants of a cold branch (rays that start outside the world) in the
+    # helper-lane instantiations; the ordered ones spill two more
+    assert field("VGPRs Spill") <= (2 if helpers else 4) and field(r"ScratchSize \[bytes/lane\]") <= (8 if helpers else 16)
     assert field(r"LDS Size \[bytes/block\]") == 16384
     lines = open(os.path.join(CSRC, "build", "trace-hip-amdgcn-amd-amdhsa-gfx950.s")).read().splitlines()
     start = next(i for i, l in enumerate(lines) if l.startswith(KERNEL) and ":" in l)
