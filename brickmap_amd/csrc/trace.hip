@@ -72,8 +72,10 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 #ifndef BM_PRIO_C
 #define BM_PRIO_C 0
 #endif
+// ticket counters of the interleaved hand-out (the XCD-aware hand-out has one per XCD: 8).  16 instead of 8: -0.3 ... -0.6 % on 1080p frames
+// (profiles/r05_counters.txt); 4: +2.5 %
 #ifndef BM_WORK_COUNTERS
-#define BM_WORK_COUNTERS 8
+#define BM_WORK_COUNTERS 16
 #endif
 #ifndef BM_QUORUM_NUM
 #define BM_QUORUM_NUM 1
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	};
 
 	bool work_left = true;
-	constexpr uint32_t kCounters = BM_WORK_COUNTERS, kCounterStride = 32; // one 128-byte line per counter
+	constexpr uint32_t kCounters = XCD ? 8u : BM_WORK_COUNTERS, kCounterStride = 32; // one 128-byte line per counter
 	// (the wave index is the same in all 64 lanes; saying so keeps everything derived from it -- the counter in use, `work_left`,
 	// the loop's exit conditions -- in scalar registers and the scheduler loop's branches scalar)
 	// XCD-aware hand-out (FrameConstants::xcd_handout, big frames): the image is cut into super-tiles of kXcdTiles x kXcdTiles tiles
