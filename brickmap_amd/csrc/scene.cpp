@@ -129,6 +129,7 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_
 	// When does a wave stop to refill?  Every refill costs the whole wave an atomic's round trip and ~110 instructions, every idle
 	// lane costs its share of all passes until then.  An item is all samples of a pixel (or ONE with BM_FLAG_SAMPLE_ITEMS): the
 	// longer it is, the rarer the refills, the earlier they pay (measured per workload, profiles/r04_refill_sweep.txt).
+	static const int refill_override = [] { const char* e = std::getenv("BM_REFILL_MIN"); return e ? std::atoi(e) : 0; }(); // tuning runs
 	const int samples_per_item = (fp->flags & BM_FLAG_SAMPLE_ITEMS) ? 1 : fp->spp;
 	fc->refill_min = samples_per_item >= 4 ? 4 : (samples_per_item >= 2 ? 8 : 16);
 	// XCD-aware hand-out: neighbouring rays behind ONE L2 instead of all eight.  Pays where the scene does not fit the caches and the
@@ -137,12 +138,14 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_
 	fc->xcd_handout = (static_cast<long long>(fc->tiles_x) * fc->tiles_y >= 32000) ? 1 : 0;
 	static const int xcd_override = [] { const char* e = std::getenv("BM_XCD_HANDOUT"); return e ? std::atoi(e) : -1; }(); // tuning runs / tests
 	if (xcd_override == 0 || xcd_override == 1) fc->xcd_handout = xcd_override;
-	static const int refill_override = [] { const char* e = std::getenv("BM_REFILL_MIN"); return e ? std::atoi(e) : 0; }(); // tuning runs
 	if (refill_override >= 1 && refill_override <= 64) fc->refill_min = refill_override;
 	// shadow rays on helper lanes (trace.hip HELP): every frame that is not ordered (above)
 	fc->helpers = ordered ? 0 : 1;
 	static const int help_override = [] { const char* e = std::getenv("BM_HELPERS"); return e ? std::atoi(e) : -1; }();
 	if (help_override == 0 || (help_override == 1 && !ordered)) fc->helpers = help_override;
+	// with helper lanes an idle lane is not wasted while it waits for the refill -- it takes shadow rays -- so the wave refills later:
+	// 24 idle lanes instead of 16 (config 2 -0.2 %, 1080p at 4 spp -1.1 %, config 3 -0.8 %; 32: worse again; profiles/r05_refill_sweep.txt)
+	if (fc->helpers && refill_override <= 0) fc->refill_min = 24;
 	{ // divisions of the hand-out by per-frame constants (trace.hip refill): multiply-high + shift
 		auto set = [](uint32_t d, uint32_t* magic, int* shift) { if (d <= 1u) { *magic = 0u; *shift = 0; } else division_magic(d, magic, shift); };
 		set((fp->flags & BM_FLAG_SAMPLE_ITEMS) ? static_cast<uint32_t>(std::max(fp->spp, 1)) : 1u, &fc->div_samples_magic, &fc->div_samples_shift);
