@@ -19,9 +19,11 @@ namespace bm {
 //
 // Work distribution: the shard's pixels are cut into 4x4-pixel chunks (ordered so that four consecutive
 // chunks form an 8x8 block and sixteen a 16x16 tile).  Waves are persistent: whenever FrameConstants::refill_min or more of a
-// wave's lanes have no pixel (16 for one-sample items, fewer for long ones), the wave takes that many pixels, pixel by pixel through consecutive 4x4 chunks, from a global
-// counter (one atomic per refill) and hands one pixel to each idle lane.  A lane traces ALL samples of its pixel, in order, before
-// it takes another one, so each pixel's accumulation order is fixed (sample by sample, event by event).
+// wave's lanes have no work item (24 with helper lanes; in ordered frames 16 for one-sample items, fewer for long ones), the wave takes that
+// many items, pixel by pixel through consecutive 4x4 chunks, from a global counter (one atomic per refill) and hands one to each idle
+// lane.  ORDERED frames (BM_FLAG_ORDERED, hit records): an item is a pixel, the lane traces ALL its samples in order before it takes
+// another one, so each pixel's accumulation order is fixed (sample by sample, event by event).  Production frames: an item is one
+// sample of a pixel, shadow rays may run on helper lanes (HELP below), every event is added to the pixel with float atomics.
 //
 // Path state machine per lane:
 //   GEN -> [extend ray] -> EXT_DONE (shade) -> [shadow ray] -> SHD_DONE (connect) -> BOUNCE -> [extend ray] ...
