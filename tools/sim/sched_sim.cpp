@@ -201,6 +201,7 @@ struct Wave {
 	double ready = 0;
 	int my_counter = 0, counters_done = 0;
 	bool work_left = true, done = false;
+	std::vector<uint32_t> mailbox; // offload=2: shadow rays waiting for an idle lane of this wave (ray indices)
 	bool second = false; // two-launch model: this wave slot now runs a workgroup of the second launch
 	double t_dry = -1, t_end = 0;
 };
@@ -241,7 +242,7 @@ struct Sim {
 		}
 		for (int i = 0; i < (int)slots.size(); ++i) nI += (slots[i].st == S_IDLE && !slots[i].busy && (i % K) < k_eff);
 		double sched_instr = P.cSched * P.schedMul;
-		if (w.work_left && nI >= P.refill_min) {
+		if (w.work_left && nI >= P.refill_min && !(P.offload == 2 && !w.mailbox.empty())) {
 			if (P.pool && nI > 64) nI = 64; // one idle slot per column and refill
 			const int want = std::max(1, (nI - P.reserve) / 4);
 			const uint32_t total_groups = (total_chunks + 3u) >> 2;
@@ -330,6 +331,12 @@ struct Sim {
 			}
 			nJ += j; nO += (o && !j); nB += b; nC += c; live += (j || o || b || c);
 		}
+		if (P.offload == 2 && !w.mailbox.empty()) { // idle lanes with mail waiting want a shade pass
+			int idle_n = 0; for (auto& sl : slots) idle_n += (sl.st == S_IDLE && !sl.busy);
+			const int take = std::min<int>(idle_n, (int)w.mailbox.size());
+			nC += take; live += take;
+			if (take == 0 && live == 0) live = 1; // (cannot happen: mail exists only while its senders' paths or other lanes live; guard)
+		}
 		const int nA = nJ + nO;
 		if (live == 0 || (P.pool && busy_live > 0 && std::max(nA, std::max(nB, nC)) < P.minfill)) {
 			if (live == 0 && busy_live == 0 && !w.work_left) {
@@ -366,6 +373,16 @@ struct Sim {
 		};
 		if (phase == 2) {
 			int n = 0, handed = 0;
+			if (P.offload == 2) {
+				for (int l2 = 0; l2 < 64 && !w.mailbox.empty(); ++l2) {
+					Slot& sl = slots[l2];
+					if (sl.st != S_IDLE || sl.busy) continue;
+					sl.next_ray = w.mailbox.back(); w.mailbox.pop_back();
+					sl.ray_end = sl.next_ray + 1; sl.ray = &g_rays[sl.next_ray++]; sl.helper = true;
+					sl.st = setup(sl, *sl.ray, P);
+					claim(&sl); n++;
+				}
+			}
 			for (int l = 0; l < 64; ++l) {
 				Slot* s = pick(l, [](int st) { return st == S_NEED; });
 				if (!s) continue;
@@ -376,6 +393,7 @@ struct Sim {
 					// the next ray is a shadow ray: an idle lane of the wave takes it, the owner continues with what follows
 					Slot* idle = nullptr;
 					for (int l2 = 0; l2 < 64 && !idle; ++l2) if (slots[l2].st == S_IDLE && !slots[l2].busy) idle = &slots[l2];
+					if (!idle && P.offload == 2) { w.mailbox.push_back(s->next_ray); s->next_ray++; handed++; }
 					if (idle) {
 						idle->next_ray = s->next_ray; idle->ray_end = s->next_ray + 1; idle->ray = &g_rays[idle->next_ray++];
 						idle->helper = true;
