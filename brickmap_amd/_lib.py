@@ -14,7 +14,6 @@ LIB_PATH = os.path.join(_HERE, "libbrickmap_hip.so")
 BM_FLAG_PRIMARY_ONLY = 1
 BM_FLAG_SAMPLE_ITEMS = 4
 BM_FLAG_COUNTERS = 2
-BM_FLAG_KSLOT = 8
 BM_FLAG_ORDERED = 16
 BRICK_INDEX_BITS = 0x00000FFF
 BRICK_LOD_BITS = 0x000FF000

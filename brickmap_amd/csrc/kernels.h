@@ -10,12 +10,6 @@ int trace_blocks_per_cu(bool instrumented, bool xcd_handout, bool helpers); // r
 // blocks_per_cu_cap: 0 = as many workgroups per CU as the instantiation keeps resident; > 0 = at most that many (tuning runs)
 void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameConstants* fc_dev, float* accum, uint32_t* dbg, DeviceCounters* counters,
 				  uint32_t* work_counter, bool instrumented, int compute_units, int blocks_per_cu_cap, hipStream_t stream);
-// K-slot schedule (trace_k.hip): K paths per lane, path state in LDS + a per-launch scratch buffer
-int trace_k_blocks_per_cu(bool instrumented);
-int trace_k_slots();
-size_t trace_k_scratch_bytes(bool instrumented, int resident_blocks);
-void launch_trace_k(const DeviceScene& sc, const FrameConstants& fc, const FrameConstants* fc_dev, float* accum, uint32_t* dbg, DeviceCounters* counters,
-					uint32_t* work_counter, bool instrumented, int resident_blocks, void* scratch, hipStream_t stream);
 void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const uint32_t* indices_queue, uint32_t* arena, uint32_t count,
 				   hipStream_t stream);
 void launch_pool_moves(const PoolMove* moves, uint32_t count, uint32_t* arena, uint32_t* pool_base, hipStream_t stream);

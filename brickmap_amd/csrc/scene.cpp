@@ -49,15 +49,19 @@ float sun_intensity(float zenith_cos) {
 
 void division_magic(uint32_t d, uint32_t* magic, int* shift);
 
-int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_in, FrameConstants* fc, bool hit_records, bool kslot) {
+int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_in, FrameConstants* fc, bool hit_records) {
 	if (!fp_in) { set_error("null argument"); return BM_EINVAL; }
+	if (fp_in->flags & ~(BM_FLAG_PRIMARY_ONLY | BM_FLAG_COUNTERS | BM_FLAG_SAMPLE_ITEMS | BM_FLAG_ORDERED)) {
+		set_error("unknown frame flag (bit 8 was the retired K-slot schedule's)");
+		return BM_EINVAL;
+	}
 	// Which frames are ORDERED (every pixel's events accumulated in path order by one lane, one plain write-back: reproducible sums)?
-	// Those that ask for it, those that write hit records, K-slot frames, primary-only frames.  Every other frame -- the production
+	// Those that ask for it, those that write hit records, primary-only frames.  Every other frame -- the production
 	// default -- may add in any order, like the reference's own atomicAdds (kernel.cu:319-322,341-343): it runs with helper lanes
 	// (trace.hip HELP) and, when a pixel has several samples, with (4x4 chunk, sample) work items: shorter items, a shorter tail,
 	// coherent neighbouring samples (1080p at 4 spp 4.0 -> 3.4 ms, config 3 -4 %).  BM_HELPERS=0 / 1 overrides helper lanes (A/B runs).
 	bm_frame_params promoted = *fp_in;
-	const bool ordered = (promoted.flags & (BM_FLAG_ORDERED | BM_FLAG_PRIMARY_ONLY)) != 0 || hit_records || kslot || promoted.spp < 1; // (spp = 0: nothing to trace)
+	const bool ordered = (promoted.flags & (BM_FLAG_ORDERED | BM_FLAG_PRIMARY_ONLY)) != 0 || hit_records || promoted.spp < 1; // (spp = 0: nothing to trace)
 	if (!ordered && promoted.spp >= 2) promoted.flags |= BM_FLAG_SAMPLE_ITEMS;
 	const bm_frame_params* const fp = &promoted;
 	if (!cam || !fp || !fc) { set_error("null argument"); return BM_EINVAL; }
@@ -248,9 +252,6 @@ int Scene::init(int grid_size, int grid_height) {
 	BM_HIP(hipGetDeviceProperties(&prop, device_));
 	compute_units_ = prop.multiProcessorCount; // main.cpp:97 sm_cores
 	blocks_per_cu_[0] = blocks_per_cu_[1] = 0; // no cap: every instantiation of the fused kernel runs at its own occupancy (trace.hip launch_trace)
-	blocks_per_cu_k_[0] = trace_k_blocks_per_cu(false);
-	blocks_per_cu_k_[1] = trace_k_blocks_per_cu(true);
-	if (const char* sch = std::getenv("BM_SCHEDULE")) kslot_default_ = std::strcmp(sch, "kslot") == 0;
 	if (const char* cap = std::getenv("BM_TRACE_BLOCKS_PER_CU")) { // experiment knob: fewer resident waves per SIMD (1 block = 1 wave per SIMD)
 		const int n = std::atoi(cap);
 		if (n > 0) blocks_per_cu_[0] = n;
@@ -702,7 +703,6 @@ int Scene::frame_begin(hipStream_t stream) {
 			for (size_t i = 1; i < frame_streams_.size(); ++i) if (frame_streams_[i].last_use < frame_streams_[lru].last_use) lru = i;
 			BM_HIP(hipEventSynchronize(frame_streams_[lru].done));
 			BM_HIP(hipEventDestroy(frame_streams_[lru].done));
-			if (frame_streams_[lru].kslot_scratch) (void)hipFree(frame_streams_[lru].kslot_scratch);
 			frame_streams_.erase(frame_streams_.begin() + static_cast<long>(lru));
 		}
 		FrameStream f;
@@ -747,10 +747,8 @@ int Scene::order_load_stream_behind_frames() {
 }
 
 void Scene::drop_frame_streams() {
-	for (FrameStream& f : frame_streams_) {
+	for (FrameStream& f : frame_streams_)
 		if (f.done) (void)hipEventDestroy(f.done);
-		if (f.kslot_scratch) (void)hipFree(f.kslot_scratch);
-	}
 	frame_streams_.clear();
 }
 
@@ -963,8 +961,7 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
 	if (!accum) { set_error("null accumulation buffer"); return BM_EINVAL; }
 	FrameConstants fc;
-	const bool kslot = kslot_default_ || (fp && (fp->flags & BM_FLAG_KSLOT));
-	if (int e = fill_frame_constants(cam, fp, &fc, dbg != nullptr, kslot)) return e;
+	if (int e = fill_frame_constants(cam, fp, &fc, dbg != nullptr)) return e;
 	BM_HIP(hipSetDevice(device_));
 	// `stream` is used as given: nullptr is HIP's default stream (what the reference's <<<>>> launches use), which is
 	// ordered with the caller's other default-stream work (e.g. torch's fill kernels on the accumulation buffer).
@@ -985,28 +982,8 @@ int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum,
 #else
 	DeviceCounters* const counters_arg = (fp->flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr;
 #endif
-	if (kslot_default_ || (fp->flags & BM_FLAG_KSLOT)) {
-		// the K-slot schedule packs a path's sample index (16 bits) and bounce count (4 bits) into one word (trace_k.hip path flags)
-		if (fp->max_bounces > 15 || fp->spp > 65535) {
-			set_error("K-slot schedule: max_bounces is limited to 15 and spp to 65535 per launch (the default schedule has no such limit)");
-			return BM_EINVAL;
-		}
-		// K-slot schedule: the launch keeps its path records in a scratch buffer of the stream it runs on
-		const int resident = compute_units_ * blocks_per_cu_k_[instrumented ? 1 : 0];
-		const size_t need = trace_k_scratch_bytes(instrumented, resident);
-		FrameStream* fs = nullptr;
-		for (FrameStream& f : frame_streams_) if (f.stream == stream) { fs = &f; break; }
-		if (!fs) { set_error("frame stream missing"); return BM_ESTATE; }
-		if (fs->kslot_scratch_bytes < need) {
-			if (fs->kslot_scratch) { BM_HIP(hipStreamSynchronize(stream)); BM_HIP(hipFree(fs->kslot_scratch)); fs->kslot_scratch = nullptr; fs->kslot_scratch_bytes = 0; }
-			BM_HIP(hipMalloc(&fs->kslot_scratch, need));
-			fs->kslot_scratch_bytes = need;
-		}
-		launch_trace_k(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, work_counter, instrumented, resident, fs->kslot_scratch, stream);
-	} else {
-		launch_trace(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, work_counter, instrumented,
-					 compute_units_, blocks_per_cu_[instrumented ? 1 : 0], stream);
-	}
+	launch_trace(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, work_counter, instrumented,
+				 compute_units_, blocks_per_cu_[instrumented ? 1 : 0], stream);
 	BM_HIP(hipGetLastError());
 	BM_HIP(hipEventRecord(ev_stop_[slot], stream));
 	if (int e = frame_end(stream)) return e; // what process_load_queue orders itself behind

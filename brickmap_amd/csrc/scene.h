@@ -63,8 +63,8 @@ public:
 	World world;
 	int device() const { return device_; }
 
-	// hit_records: the frame writes per-pixel hit records; kslot: it runs the K-slot schedule -- both make it an ORDERED frame (scene.cpp)
-	static int fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp, FrameConstants* fc, bool hit_records = false, bool kslot = false);
+	// hit_records: the frame writes per-pixel hit records, which makes it an ORDERED frame (scene.cpp)
+	static int fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp, FrameConstants* fc, bool hit_records = false);
 
 private:
 	int allocate_device();
@@ -90,8 +90,6 @@ private:
 		hipEvent_t done = nullptr;
 		uint64_t upload_seen = 0;
 		uint64_t last_use = 0;
-		void* kslot_scratch = nullptr;   // K-slot schedule (trace_k.hip): the launch's path records; launches on one stream run one after the other
-		size_t kslot_scratch_bytes = 0;
 	};
 	static constexpr size_t kMaxFrameStreams = 16;
 	std::vector<FrameStream> frame_streams_;
@@ -121,8 +119,6 @@ private:
 	FrameConstants* h_frame_constants_ = nullptr; // pinned source of the copies
 	uint32_t* d_work_counter_ = nullptr; // chunk counters of the persistent trace kernel: kTimingRing blocks, one per launch, zeroed before it
 	int compute_units_ = 0, blocks_per_cu_[2] = {0, 0};
-	int blocks_per_cu_k_[2] = {0, 0}; // K-slot schedule
-	bool kslot_default_ = false;      // BM_SCHEDULE=kslot: every frame runs the K-slot schedule (otherwise BM_FLAG_KSLOT selects it per frame)
 	// pinned staging (Scene.cpp:30-32)
 	int* h_positions_[2] = {nullptr, nullptr};
 	uint32_t* h_bricks_ = nullptr;

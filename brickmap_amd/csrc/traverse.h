@@ -129,11 +129,8 @@ __device__ __forceinline__ float& staging_word(unsigned long long* lds_brick, ui
 	return f[((j >> 1) * 256u + t) * 2u + (j & 1u)];                      // half j & 1 of slice j / 2 of thread t
 }
 
-// OVERLAY (trace_k.hip): the brick is staged in four 16-byte chunks 4 KiB apart that belong to the calling thread alone
-// (`lds_brick` points at the first): slice z is the 64-bit half (z & 1) of chunk z >> 1.
-template <bool OVERLAY>
+// z-slice (one 64-bit word: bit x + 8y) of the calling thread's staged brick
 __device__ __forceinline__ unsigned long long brick_slice(const unsigned long long* lds_brick, uint32_t z) {
-	if (OVERLAY) return lds_brick[(z >> 1) * 512u + (z & 1u)];
 	if (BM_LDS_DMA == 2) return lds_brick[(z >> 1) * 512u + threadIdx.x * 2u + (z & 1u)];
 	if (BM_LDS_DMA) {
 		const uint32_t* w = reinterpret_cast<const uint32_t*>(lds_brick) + z * 512u + threadIdx.x;
@@ -141,7 +138,7 @@ __device__ __forceinline__ unsigned long long brick_slice(const unsigned long lo
 	}
 	return lds_brick[z * 256u + threadIdx.x];
 }
-template <int N, bool DBG, bool OVERLAY = false>
+template <int N, bool DBG>
 __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy, int sz, float dx, float dy, float dz, f3& normal, float& distance,
 											   const BrickRegs& brick, uint32_t byte, int& sub_id, Tally& tally, unsigned long long* lds_brick = nullptr,
 											   uint32_t* trips = nullptr, const uint32_t* brick_words = nullptr) {
@@ -169,10 +166,7 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 		return (byte >> ((c & 1u) | ((c >> 4) & 2u) | ((c >> 8) & 4u))) & 1u;                                  // bit x + 2y + 4z of the LoD mask
 	};
 	if (N == 8) {
-		if (OVERLAY) {
-			uint4* q = reinterpret_cast<uint4*>(lds_brick);
-			q[0] = brick.q0; q[256] = brick.q1; q[512] = brick.q2; q[768] = brick.q3;
-		} else if (BM_LDS_DMA == 2) {
+		if (BM_LDS_DMA == 2) {
 			brick_dma4_to_lds(lds_brick, brick_words);
 		} else if (BM_LDS_DMA) {
 			brick_dma_to_lds(lds_brick, brick_words);
@@ -180,7 +174,7 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 			brick_to_lds(lds_brick, brick);
 		}
 	}
-	unsigned long long slice = N == 8 ? brick_slice<OVERLAY>(lds_brick, (cell >> 10) & 7u) : 0ull;
+	unsigned long long slice = N == 8 ? brick_slice(lds_brick, (cell >> 10) & 7u) : 0ull;
 	if (DBG) tally.voxel_steps++;
 	bool solid = test(cell, slice);
 	bool inside = true;
@@ -198,7 +192,7 @@ __device__ __forceinline__ bool intersect_grid(f3 origin, f3 dir, int sx, int sy
 		tx += mx ? dx : 0.f;
 		ty += my ? dy : 0.f;
 		tz += mz ? dz : 0.f;
-		if (N == 8) slice = brick_slice<OVERLAY>(lds_brick, (cell >> 10) & 7u);
+		if (N == 8) slice = brick_slice(lds_brick, (cell >> 10) & 7u);
 		if (DBG && inside) tally.voxel_steps++;
 		solid = static_cast<bool>(static_cast<int>(inside) & static_cast<int>(test(cell, slice))); // no branch: (cell's fields are masked, any value is safe to test)
 	}
@@ -231,7 +225,6 @@ struct RayState {
 	float tminn;
 	f3 n;               // normal carried in/out of the traversal (voxel.cuh:135 `normal`)
 	int last_step;      // offset increment of the last move (0 before the first): which axis it was, see move_axis
-	int last_axis;      // the same as an axis number (-1 before the first move): what trace_k.hip keeps instead of last_step
 	uint32_t field_off;      // byte offset of the ray's octant plane in DeviceScene::cube_field
 	uint32_t cube;           // edge of the empty cube ahead of the current cell (its cube_field byte)
 	float distance;     // result
@@ -278,8 +271,8 @@ __device__ __forceinline__ int move_axis(const DeviceScene& sc, int last_step) {
 #define BM_JUMP_MIN 4 // smallest cube edge worth a jump (a jump costs about four single steps)
 #endif
 constexpr uint32_t kCubeNoJump = 0x100u; // RayState::cube flag: tmax is outside the range of jump.h, take single moves
-// The lookup in three pieces -- where the cell's byte lives, whether a jump may start from the current tmax, what the byte means
-// -- so that a kernel can issue the load in one pass and use the byte in a later one (trace_k.hip); field_lookup is their sum.
+// The lookup in three pieces -- where the cell's byte lives, whether a jump may start from the current tmax, what the byte means;
+// field_lookup is their sum.
 __device__ __forceinline__ uint32_t field_index(const DeviceScene& sc, const RayState& r) {
 	return r.p; // the cell IS its entry's offset (cell_offset)
 }
@@ -312,7 +305,6 @@ __device__ __forceinline__ void step_advance(RayState& r) {
 	const int step = mx ? step_x : (my ? step_y : step_z);
 	r.p += static_cast<uint32_t>(step);
 	r.last_step = step;
-	r.last_axis = mx ? 0 : (my ? 1 : 2);
 	r.tx = tx + (mx ? r.dx : 0.f);
 	r.ty = ty + (my ? r.dy : 0.f);
 	r.tz = tz + (mz ? r.dz : 0.f);
@@ -347,7 +339,6 @@ __device__ __forceinline__ uint32_t jump_advance(RayState& r) {
 	// all three products fit 24-bit signed multiplies: counts <= 255, increments +-1 / +- row pitch / +- slice pitch (< 2^23, Scene::init checks)
 	r.p += static_cast<uint32_t>(__mul24(static_cast<int>(cx), step_x) + __mul24(static_cast<int>(cy), step_y) + __mul24(static_cast<int>(cz), step_z));
 	r.last_step = axis == 0 ? step_x : (axis == 1 ? step_y : step_z); // (only read after a cube exit, where it is the exit axis)
-	r.last_axis = axis;
 	return cx + cy + cz;
 }
 template <bool DBG, bool DIR = true>
@@ -459,15 +450,12 @@ __device__ __forceinline__ int ray_setup(const DeviceScene& sc, f3 origin, const
 	r.tz = dir.z != 0.f ? (cbz - origin.z) * rz : 1000000.f;
 	r.dx = static_cast<float>(sx) * rx; r.dy = static_cast<float>(sy) * ry; r.dz = static_cast<float>(sz) * rz;
 	r.last_step = 0;
-	r.last_axis = -1;
 	if (DBG) tally.index_loads++; // one per visited cell = the reference's index loads (algorithmic count)
 	return field_lookup(sc, r); // inside the grid: never a border cell
 }
 
 // voxel.cuh:200-247: the current cell holds a non-empty brick -- read its index word and resolve it.
-// AXIS: the axis of the last move comes from r.last_axis (trace_k.hip) instead of the packed increment r.last_step.
-// OVERLAY: brick staging layout, see intersect_grid.
-template <bool DBG, bool AXIS = false, bool OVERLAY = false>
+template <bool DBG>
 __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const int* campos, RayState& r, HitInfo& info, Tally& tally,
 													 unsigned long long* lds_brick, uint32_t* walk_trips = nullptr) {
 	int px, py, pz;
@@ -486,7 +474,7 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 	brick.q0 = brick.q1 = brick.q2 = brick.q3 = make_uint4(0u, 0u, 0u, 0u);
 	// voxel.cuh:202-206, by select: entry normal and entry distance from the axis of the last move; a ray that starts
 	// inside this cell (no move yet) keeps its normal and enters at distance 0
-	const int axis = AXIS ? r.last_axis : move_axis(sc, r.last_step);
+	const int axis = move_axis(sc, r.last_step);
 	const float new_distance = axis == 0 ? r.tx - r.dx : (axis == 1 ? r.ty - r.dy : (axis == 2 ? r.tz - r.dz : 0.f));
 	r.n = mk(axis == -1 ? r.n.x : (axis == 0 ? -static_cast<float>(sx) : 0.f), axis == -1 ? r.n.y : (axis == 1 ? -static_cast<float>(sy) : 0.f),
 			 axis == -1 ? r.n.z : (axis == 2 ? -static_cast<float>(sz) : 0.f));
@@ -514,8 +502,8 @@ __device__ __forceinline__ int process_candidate(const DeviceScene& sc, const in
 		int sub = 0;
 		const f3 o8 = (r.o + r.d * new_distance) * 8.f - r.n * kEpsilon;
 		const uint4* bq = reinterpret_cast<const uint4*>(sc.brick_arena + (static_cast<size_t>(pool + (index & kIndexBits)) << 4));
-		if (OVERLAY || !BM_LDS_DMA) { brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3]; }
-		if (intersect_grid<8, DBG, OVERLAY>(o8, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick, walk_trips, reinterpret_cast<const uint32_t*>(bq))) {
+		if (!BM_LDS_DMA) { brick.q0 = bq[0]; brick.q1 = bq[1]; brick.q2 = bq[2]; brick.q3 = bq[3]; }
+		if (intersect_grid<8, DBG>(o8, r.d, sx, sy, sz, r.dx, r.dy, r.dz, r.n, sub_distance, brick, 0u, sub, tally, lds_brick, walk_trips, reinterpret_cast<const uint32_t*>(bq))) {
 			r.distance = new_distance * 8.f + sub_distance + r.tminn;
 			if (DBG) { info.level = 2; info.sub_id = sub; }
 			r.hit = true;

@@ -47,9 +47,7 @@ extern "C" {
                                    faster mode of any frame with several samples per pixel (1080p at 4 spp: 3.7 ms against 4.4,
                                    4K at 4 spp: 23.0 against 24.0 -- shorter items, shorter tail) when a fixed summation order is not needed */
 
-#define BM_FLAG_KSLOT 8u        /* run this frame with the K-slot schedule (csrc/trace_k.hip: K paths per lane, path state in LDS):
-                                   same paths, same per-pixel event order, hit records bit-identical to the default schedule's
-                                   (the environment variable BM_SCHEDULE=kslot selects it for every frame of the process) */
+/* (8u: retired -- the K-slot schedule of rounds 4-5, tools/variants/kslot.patch; unknown bits are refused with BM_EINVAL) */
 
 #define BM_FLAG_ORDERED 16u     /* every pixel's events are accumulated in path order by the one lane that owns it and written back with
                                    one plain store: a frame's sums are reproducible bit for bit.  WITHOUT this flag (the default) a wave
@@ -58,7 +56,7 @@ extern "C" {
                                    connect does (kernel.cu:341-343), and radiance is equal up to summation order (~1e-7 relative); and a
                                    frame with several samples per pixel is scheduled as (4x4 chunk, sample) work items, as if
                                    BM_FLAG_SAMPLE_ITEMS were set (1080p at 4 spp: 3.4 ms against 4.0).
-                                   Frames that write hit records (debug_dev != NULL), K-slot frames and primary-only frames are always ordered. */
+                                   Frames that write hit records (debug_dev != NULL) and primary-only frames are always ordered. */
 
 typedef struct bm_scene bm_scene; /* Scene + its GPUScene view (Scene.h:7-44), one GPU */
 

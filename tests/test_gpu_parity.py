@@ -39,18 +39,15 @@ def gpu_render(bm, torch, scene, cam, params, accum=None, want_dbg=True, also_pl
           the kernel bench.py times): identical terminated-path counts, radiance equal up to summation order (2e-5);
       (c) where the caller checks traversal counters (BM_FLAG_COUNTERS on a resident scene with clean counters): with helper lanes AND
           counters, instrumented, no hit records -- the counters must equal the ordered frame's, i.e. the helpers walked the same rays;
-      (d) twice more with the K-slot schedule (BM_FLAG_KSLOT, csrc/trace_k.hip: instrumented and production instantiation): same
-          accumulator bits, same hit records.
-    So every case that checks the instrumented kernel against the oracle also pins the benchmarked one and both schedules."""
+    So every case that checks the instrumented kernel against the oracle also pins the benchmarked one."""
     import copy
     rows = bm.local_rows(params)
     if accum is None:
         accum = torch.zeros((rows, params.width, 4), dtype=torch.float32, device="cuda:0")
-    check_kslot = os.environ.get("BM_TEST_KSLOT", "1") != "0" and not (params.flags & bm.BM_FLAG_KSLOT)
-    before = accum.clone() if (also_plain or check_kslot) else None
+    before = accum.clone() if also_plain else None
     dbg = torch.zeros((rows, params.width, 8), dtype=torch.int32, device="cuda:0") if want_dbg else None
     helper_counts = helper_acc = None
-    if want_dbg and (params.flags & bm.BM_FLAG_COUNTERS) and not (params.flags & (bm.BM_FLAG_ORDERED | bm.BM_FLAG_KSLOT)):
+    if want_dbg and (params.flags & bm.BM_FLAG_COUNTERS) and not (params.flags & bm.BM_FLAG_ORDERED):
         # the caller compares the scene's counters with the oracle's after this call: render the frame once with helper lanes AND
         # counters first (instrumented instantiation, no hit records), keep its counts, and hand the caller a clean slate.  Only when
         # the counters are clean and the scene is fully resident (an extra frame of a streaming scene changes what is requested).
@@ -95,27 +92,6 @@ def gpu_render(bm, torch, scene, cam, params, accum=None, want_dbg=True, also_pl
         assert scene.counters() == helper_counts, "helper lanes: traversal counters differ from the ordered frame's"
         assert np.array_equal(helper_acc[..., 3], a[..., 3])
         np.testing.assert_allclose(helper_acc[..., :3], a[..., :3], rtol=2e-5, atol=1e-7, err_msg="helper lanes (instrumented): radiance differs")
-    if check_kslot:
-        atomic_sum = bool(params.flags & bm.BM_FLAG_SAMPLE_ITEMS)  # samples of a pixel are added with float atomics: order not fixed
-        # (without BM_FLAG_COUNTERS: the scene's traversal counters belong to the caller's own frames; test_kslot_counters pins the K-slot ones)
-        variants = [((params.flags & ~bm.BM_FLAG_COUNTERS) | bm.BM_FLAG_KSLOT, want_dbg)]
-        if want_dbg and also_plain:
-            variants.append(((params.flags & ~bm.BM_FLAG_COUNTERS) | bm.BM_FLAG_KSLOT, False))
-        for flags, with_dbg in variants:
-            kp = copy.copy(params)
-            kp.flags = flags
-            acc_k = before.clone()
-            dbg_k = torch.zeros((rows, params.width, 8), dtype=torch.int32, device="cuda:0") if with_dbg else None
-            scene.render(cam, kp, acc_k, debug=dbg_k)
-            torch.cuda.synchronize()
-            k = acc_k.cpu().numpy()
-            if atomic_sum:
-                np.testing.assert_allclose(k, a, rtol=2e-5, atol=1e-7, err_msg="K-slot schedule: radiance differs")
-                assert np.array_equal(k[..., 3], a[..., 3]), "K-slot schedule: terminated-path counts differ"
-            else:
-                assert np.array_equal(k.view(np.uint32), a.view(np.uint32)), "K-slot schedule: accumulator differs from the default schedule's"
-            if with_dbg:
-                assert np.array_equal(dbg_k.cpu().numpy().view(np.uint32), dbg.cpu().numpy().view(np.uint32)), "K-slot schedule: hit records differ"
     return a, (dbg.cpu().numpy().view(np.uint32) if want_dbg else None)
 
 
@@ -1176,36 +1152,19 @@ def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda, tmp_path):
         port += 1
 
 
-def test_long_paths_and_schedule_limits(bm, orc, torch_cuda, scene256, world256):
-    """max_bounces = 16 (17 segments per path): the default schedule has no limit and matches the oracle; the K-slot schedule packs
-    the bounce count into 4 bits and the sample index into 16 and must REFUSE what it cannot represent (BM_EINVAL) instead of
-    rendering a wrong image; and a frame whose tickets would wrap the 32-bit hand-out counters is refused as well."""
-    import copy
+def test_long_paths_and_ticket_limits(bm, orc, torch_cuda, scene256, world256):
+    """max_bounces = 16 (17 segments per path): the schedule has no limit on the path length and matches the oracle; a frame whose
+    tickets would wrap the 32-bit hand-out counters is refused when the caller ASKED for (chunk, sample) items, and rendered with pixel
+    items (which carry no spp factor) when the items were only the library's own choice."""
     torch = torch_cuda
     cam, ocam = cameras(bm, orc, 256)
     W, H = 96, 64
     p = bm.FrameParams(W, H, spp=1, max_bounces=16)
-    os.environ["BM_TEST_KSLOT"] = "0"
-    try:
-        a, dbg = gpu_render(bm, torch, scene256, cam, p)
-    finally:
-        os.environ.pop("BM_TEST_KSLOT", None)
+    a, dbg = gpu_render(bm, torch, scene256, cam, p)
     oacc, odbg, _, _ = world256.render(ocam, orc.make_frame(W, H, spp=1, max_bounces=16))
     assert np.array_equal(dbg, odbg)
     assert_radiance(a, oacc)
-    assert int((dbg[..., 6] & 0xFFFF).max()) > 5  # some paths really are longer than the K-slot schedule's old silent limit allows to matter
-    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
-    for bad in (bm.FrameParams(W, H, spp=1, max_bounces=16, flags=bm.BM_FLAG_KSLOT), bm.FrameParams(W, H, spp=65536, max_bounces=3, flags=bm.BM_FLAG_KSLOT)):
-        with pytest.raises(Exception) as e:
-            scene256.render(cam, bad, acc)
-        assert "K-slot" in str(e.value)
-    ok = bm.FrameParams(W, H, spp=1, max_bounces=15, flags=bm.BM_FLAG_KSLOT)
-    acc_k = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
-    scene256.render(cam, ok, acc_k)
-    acc_d = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
-    scene256.render(cam, bm.FrameParams(W, H, spp=1, max_bounces=15, flags=bm.BM_FLAG_ORDERED), acc_d)
-    torch.cuda.synchronize()
-    assert torch.equal(acc_k.view(torch.int32), acc_d.view(torch.int32))
+    assert int((dbg[..., 6] & 0xFFFF).max()) > 5  # some paths really are long
     # 32-bit ticket counters: (chunk, sample) items of a 4K frame at 100 000 spp would wrap them
     with pytest.raises(Exception) as e:
         scene256.render(cam, bm.FrameParams(3840, 2160, spp=100000, max_bounces=3, flags=bm.BM_FLAG_SAMPLE_ITEMS), torch.zeros((2160, 3840, 4), dtype=torch.float32, device="cuda:0"))
@@ -1263,25 +1222,6 @@ def test_frames_overlapping_on_two_streams(bm, orc, torch_cuda, scene256):
     a, b = got.cpu().numpy(), want.cpu().numpy()
     assert np.array_equal(a[..., 3], b[..., 3])  # terminated paths per pixel: exact in any order
     np.testing.assert_allclose(a[..., :3], b[..., :3], rtol=2e-6, atol=1e-9)
-
-
-def test_kslot_counters(bm, torch_cuda, scene256, world256, orc):
-    """The K-slot schedule (BM_FLAG_KSLOT) visits the same cells, tests the same bricks and traces the same rays as the oracle:
-    its traversal counters are the oracle's exactly (and therefore the default schedule's)."""
-    torch = torch_cuda
-    W, H = 160, 120
-    cam, ocam = cameras(bm, orc, 256)
-    _, _, ocnt, _ = world256.render(ocam, orc.make_frame(W, H, spp=2, max_bounces=3))
-    scene256.counters_reset()
-    acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
-    scene256.render(cam, bm.FrameParams(W, H, spp=2, max_bounces=3, flags=bm.BM_FLAG_COUNTERS | bm.BM_FLAG_KSLOT), acc)
-    torch.cuda.synchronize()
-    got = scene256.counters()
-    for name in ("index_loads", "brick_tests", "byte_tests", "voxel_steps", "extend_rays", "shadow_rays", "paths"):
-        assert got[name] == ocnt[name], (name, got[name], ocnt[name])
-    st = scene256.sched_stats()
-    assert st["waves"] > 0 and st["jump_runs"] > 0 and st["candidate_runs"] > 0 and st["shade_runs"] > 0
-    scene256.counters_reset()
 
 
 @pytest.mark.gpu

@@ -25,7 +25,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-KERNEL = os.environ.get("BM_PROFILE_KERNEL", "trace_paths<false,")  # (both hand-out instantiations: <false, false> and, on big frames, <false, true>)  # BM_SCHEDULE=kslot BM_PROFILE_KERNEL="trace_paths_k<false>" profiles the K-slot schedule
+KERNEL = os.environ.get("BM_PROFILE_KERNEL", "trace_paths<false,")  # (both hand-out instantiations: <false, false> and, on big frames, <false, true>)
 FETCH_FACTOR = 1.0  # profiles/r03_fetch_calibration.txt: single-sector requests are counted at their true 64 bytes
 PMC_SETS = [
     "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY",

@@ -1,7 +1,7 @@
 """Randomised parity soak (GPU box): many seeded views / suns / lenses / sample offsets / LoD thresholds on two worlds
 (256^3 and the non-cubic 384 x 384 x 128), the HIP path against the oracle: hit records bit-exact, radiance within 1e-4,
-and the production instantiation bit-identical to the instrumented one; the K-slot schedule (BM_FLAG_KSLOT, both instantiations)
-must give the same accumulator bits and the same hit records.  usage: python tools/soak_parity.py [trials=400] [seed=1]"""
+and the production instantiation bit-identical to the instrumented one; the production default (helper lanes, float atomics)
+equal up to summation order.  usage: python tools/soak_parity.py [trials=400] [seed=1]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -42,10 +42,6 @@ for t in range(trials):
     scene.render(cam, p_ord, plain)                    # production instantiation, ordered sums: the instrumented frame's bits
     prod = torch.zeros_like(acc)
     scene.render(cam, p, prod)                         # production default: helper lanes, (chunk, sample) items for spp >= 2, float atomics
-    pk = bm.FrameParams(W, H, spp=spp, sample_base=sb, max_bounces=mb, sun_position=sun, flags=bm.BM_FLAG_KSLOT)
-    acc_k, plain_k, dbg_k = torch.zeros_like(acc), torch.zeros_like(acc), torch.zeros_like(dbg)
-    scene.render(cam, pk, acc_k, debug=dbg_k)
-    scene.render(cam, pk, plain_k)
     torch.cuda.synchronize()
     oacc, odbg, _, _ = world.render(ocam, orc.make_frame(W, H, spp=spp, max_bounces=mb, sample_base=sb, sun=sun), threads=os.cpu_count() or 1)
     a, b, d = acc.cpu().numpy(), plain.cpu().numpy(), dbg.cpu().numpy().view(np.uint32)
@@ -54,8 +50,6 @@ for t in range(trials):
     both = np.isfinite(a) & np.isfinite(c)
     ok = ok and np.array_equal(np.isfinite(a), np.isfinite(c)) and np.array_equal(np.where(both, c, 0)[..., 3], np.where(both, a, 0)[..., 3]) \
         and np.allclose(np.where(both, c, 0)[..., :3], np.where(both, a, 0)[..., :3], rtol=2e-5, atol=1e-7)
-    ok = ok and np.array_equal(dbg_k.cpu().numpy().view(np.uint32), d) and np.array_equal(acc_k.cpu().numpy().view(np.uint32), a.view(np.uint32)) \
-        and np.array_equal(plain_k.cpu().numpy().view(np.uint32), a.view(np.uint32))
     fin = np.isfinite(oacc)
     ok = ok and np.array_equal(np.isfinite(a), fin)
     err = float((np.abs(np.where(fin, a, 0) - np.where(fin, oacc, 0)) / np.maximum(np.abs(np.where(fin, oacc, 0)), 1e-6)).max())
