@@ -168,11 +168,39 @@ def test_retired_experiments_stay_out_of_the_kernel_sources():
     import glob
     patches = sorted(glob.glob(os.path.join(ROOT, "tools", "variants", "*.patch")))
     assert len(patches) >= 9
-    retired = ("BM_JUMP_BINADES", "BM_LOD_PRETEST", "BM_NT_BRICKS", "BM_FIELD_BLOCKED", "BM_XCD_TILES", "BM_CMP3", "BM_B_STEP", "BM_ARGMAX", "BM_FLAG_TWIN", "coarse_field")
+    retired = ("BM_JUMP_BINADES", "BM_LOD_PRETEST", "BM_NT_BRICKS", "BM_FIELD_BLOCKED", "BM_XCD_TILES", "BM_CMP3", "BM_B_STEP", "BM_ARGMAX", "BM_FLAG_TWIN", "coarse_field",
+               "BM_FLAG_KSLOT", "trace_k", "OVERLAY")
     for f in glob.glob(os.path.join(ROOT, "brickmap_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "brickmap_amd", "csrc", "*.cpp")):
         text = open(f).read()
         for macro in retired:
             assert macro not in text, (os.path.basename(f), macro)
+
+
+def test_variant_patches_apply_to_their_base_commits(tmp_path):
+    """Every tools/variants/*.patch is listed in BASES.txt with the commit it is exact against, and applies to an export of that
+    commit (the records must not go stale unnoticed).  Needs the repository's history: skipped on a bare snapshot."""
+    import glob
+    import subprocess
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("no git history in this snapshot")
+    bases = {}
+    for line in open(os.path.join(ROOT, "tools", "variants", "BASES.txt")):
+        if line.strip() and not line.startswith("#"):
+            name, commit = line.split()
+            bases[name] = commit
+    patches = sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "tools", "variants", "*.patch")))
+    assert patches == sorted(bases), "every patch has a base commit on record"
+    for commit in sorted(set(bases.values())):
+        if subprocess.run(["git", "cat-file", "-e", commit + "^{commit}"], cwd=ROOT).returncode != 0:
+            pytest.skip(f"commit {commit} is not in this clone")
+        tree = tmp_path / commit
+        tree.mkdir()
+        tar = subprocess.run(["git", "archive", commit, "brickmap_amd", "include", "tests", "tools", "bench.py"], cwd=ROOT, capture_output=True, check=True).stdout
+        subprocess.run(["tar", "-x", "-C", str(tree)], input=tar, check=True)
+        for name in patches:
+            if bases[name] == commit:
+                r = subprocess.run(["git", "apply", "--check", os.path.join(ROOT, "tools", "variants", name)], cwd=str(tree), capture_output=True, text=True)
+                assert r.returncode == 0, (name, commit, r.stderr[-500:])
 
 
 def test_scheduler_simulator_builds_and_runs(tmp_path, orc):
