@@ -38,6 +38,11 @@ class bm_frame_params(C.Structure):
                 ("sun_position", C.c_float * 2)]
 
 
+class bm_frame_plan(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("ordered", C.c_int32), ("helpers", C.c_int32), ("sample_items", C.c_int32), ("xcd_handout", C.c_int32),
+                ("refill_min", C.c_int32), ("instrumented", C.c_int32), ("tiles_x", C.c_int32), ("tiles_y", C.c_int32), ("local_rows", C.c_int32)]
+
+
 class bm_scene_info(C.Structure):
     _fields_ = [("grid_size", C.c_int32), ("grid_height", C.c_int32), ("supergrid_xy", C.c_int32),
                 ("supergrid_z", C.c_int32), ("supercells", C.c_int32), ("queue_capacity", C.c_int32),
@@ -101,6 +106,10 @@ SIGNATURES = {
     "bm_buffer_write": (_i, [_i, _vp, _vp, C.c_size_t]),
     "bm_local_rows": (_i, [C.POINTER(bm_frame_params)]),
     "bm_render_frame": (_i, [_vp, C.POINTER(bm_camera), C.POINTER(bm_frame_params), _vp, _vp, _vp]),
+    "bm_render_frames": (_i, [_vp, _i, C.POINTER(bm_camera), C.POINTER(bm_frame_params), C.POINTER(_vp), C.POINTER(_vp), _vp]),
+    "bm_frame_plan_of": (_i, [C.POINTER(bm_frame_params), _i, C.POINTER(bm_frame_plan)]),
+    "bm_trace_waves_per_simd": (_i, [_i, _i, _i, _i, C.POINTER(C.c_int)]),
+    "bm_tuning_overrides": (_i, [C.c_char_p, C.c_size_t]),
     "bm_resolve": (_i, [_vp, _vp, _vp, C.c_int64, _vp]),
     "bm_synchronize": (_i, [_vp]),
     "bm_last_render_ms": (_i, [_vp, C.POINTER(C.c_float)]),

@@ -1,5 +1,6 @@
 // capi.cpp -- extern "C" surface of libbrickmap_hip.so (declared in include/brickmap.h).
 #include <cstring>
+#include <string>
 #include <vector>
 #include <new>
 
@@ -192,6 +193,49 @@ int bm_local_rows(const bm_frame_params* p) {
 int bm_render_frame(bm_scene* scene, const bm_camera* camera, const bm_frame_params* params, float* accum_dev, uint32_t* debug_dev, void* hip_stream) {
 	BM_NEED(scene);
 	return scene->impl.render(camera, params, accum_dev, debug_dev, static_cast<hipStream_t>(hip_stream));
+}
+int bm_render_frames(bm_scene* scene, int count, const bm_camera* cameras, const bm_frame_params* params, float* const* accum_dev, uint32_t* const* debug_dev,
+					 void* hip_stream) {
+	BM_NEED(scene);
+	return scene->impl.render_frames(count, cameras, params, accum_dev, debug_dev, static_cast<hipStream_t>(hip_stream));
+}
+int bm_frame_plan_of(const bm_frame_params* params, int hit_records, bm_frame_plan* out) {
+	if (!params || !out) { set_error("null argument"); return BM_EINVAL; }
+	bm_camera cam{};
+	cam.direction[0] = 1.f; cam.up[2] = 1.f; cam.focal_distance = 1.f; // (the plan does not depend on the view)
+	bm::FrameConstants fc;
+	if (int e = bm::Scene::fill_frame_constants(&cam, params, &fc, hit_records != 0)) return e;
+	std::memset(out, 0, sizeof *out);
+	out->flags = fc.flags;
+	out->helpers = fc.helpers;
+	out->sample_items = (fc.flags & BM_FLAG_SAMPLE_ITEMS) ? 1 : 0;
+	out->ordered = (fc.helpers || out->sample_items) ? 0 : 1;
+	out->xcd_handout = fc.xcd_handout;
+	out->refill_min = fc.refill_min;
+	out->tiles_x = fc.tiles_x; out->tiles_y = fc.tiles_y; out->local_rows = fc.local_rows;
+	out->instrumented = (hit_records || (fc.flags & BM_FLAG_COUNTERS)) ? 1 : 0;
+	return 0;
+}
+int bm_trace_waves_per_simd(int device, int instrumented, int xcd_handout, int helpers, int* waves) {
+	if (!waves) { set_error("null argument"); return BM_EINVAL; }
+	BM_HIP(hipSetDevice(device));
+	// a 256-thread workgroup is one wave on each of a compute unit's four SIMDs: resident workgroups per CU = waves per SIMD
+	*waves = bm::trace_blocks_per_cu(instrumented != 0, xcd_handout != 0, helpers != 0);
+	if (bm::tuning().blocks_per_cu > 0 && !instrumented && *waves > bm::tuning().blocks_per_cu) *waves = bm::tuning().blocks_per_cu;
+	return 0;
+}
+int bm_tuning_overrides(char* buf, size_t buflen) {
+	if (!buf || buflen == 0) { set_error("null argument"); return BM_EINVAL; }
+	const bm::Tuning& t = bm::tuning();
+	std::string s;
+	auto add = [&s](const char* name, int v) { if (!s.empty()) s += ' '; s += name; s += '='; s += std::to_string(v); };
+	if (t.refill_min >= 1 && t.refill_min <= 64) add("BM_REFILL_MIN", t.refill_min);
+	if (t.xcd_handout == 0 || t.xcd_handout == 1) add("BM_XCD_HANDOUT", t.xcd_handout);
+	if (t.helpers == 0 || t.helpers == 1) add("BM_HELPERS", t.helpers);
+	if (t.blocks_per_cu > 0) add("BM_TRACE_BLOCKS_PER_CU", t.blocks_per_cu);
+	if (s.size() + 1 > buflen) { set_error("buffer too small"); return BM_EINVAL; }
+	std::memcpy(buf, s.c_str(), s.size() + 1);
+	return 0;
 }
 int bm_resolve(bm_scene* scene, const float* accum_dev, float* out_dev, int64_t n_pixels, void* hip_stream) {
 	BM_NEED(scene);

@@ -49,6 +49,22 @@ float sun_intensity(float zenith_cos) {
 
 void division_magic(uint32_t d, uint32_t* magic, int* shift);
 
+// Tuning overrides, read from the environment ONCE per process (A/B runs, tools/): BM_REFILL_MIN (1 ... 64), BM_XCD_HANDOUT (0 / 1),
+// BM_HELPERS (0 / 1), BM_TRACE_BLOCKS_PER_CU (> 0).  None set = the product's own rules.  bm_tuning_overrides() reports them, so that
+// a measurement can say what it ran under (bench.py echoes them into its line and refuses to go on under BM_BENCH_STRICT=1).
+const Tuning& tuning() {
+	static const Tuning t = [] {
+		Tuning v;
+		auto num = [](const char* name, int unset) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : unset; };
+		v.refill_min = num("BM_REFILL_MIN", 0);
+		v.xcd_handout = num("BM_XCD_HANDOUT", -1);
+		v.helpers = num("BM_HELPERS", -1);
+		v.blocks_per_cu = num("BM_TRACE_BLOCKS_PER_CU", 0);
+		return v;
+	}();
+	return t;
+}
+
 int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_in, FrameConstants* fc, bool hit_records) {
 	if (!fp_in) { set_error("null argument"); return BM_EINVAL; }
 	if (fp_in->flags & ~(BM_FLAG_PRIMARY_ONLY | BM_FLAG_COUNTERS | BM_FLAG_SAMPLE_ITEMS | BM_FLAG_ORDERED)) {
@@ -62,7 +78,6 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_
 	// coherent neighbouring samples (1080p at 4 spp 4.0 -> 3.4 ms, config 3 -4 %).  BM_HELPERS=0 / 1 overrides helper lanes (A/B runs).
 	bm_frame_params promoted = *fp_in;
 	const bool ordered = (promoted.flags & (BM_FLAG_ORDERED | BM_FLAG_PRIMARY_ONLY)) != 0 || hit_records || promoted.spp < 1; // (spp = 0: nothing to trace)
-	if (!ordered && promoted.spp >= 2) promoted.flags |= BM_FLAG_SAMPLE_ITEMS;
 	const bm_frame_params* const fp = &promoted;
 	if (!cam || !fp || !fc) { set_error("null argument"); return BM_EINVAL; }
 	if (fp->width <= 0 || fp->height <= 0 || fp->spp < 0 || fp->max_bounces < 0 || fp->band_rows <= 0 || fp->shard_count <= 0 ||
@@ -75,6 +90,34 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_
 		set_error("frame too large: width and height are limited to 65535 and a shard to 2^32 pixels");
 		return BM_EINVAL;
 	}
+	const int geo_tiles_x = (fp->width + 15) / 16, geo_tiles_y = (bm_local_rows(fp) + 15) / 16;
+	// XCD-aware hand-out: neighbouring rays behind ONE L2 instead of all eight.  Pays where the scene does not fit the caches and the
+	// frame has enough 256x256-pixel super-tiles for eight even shares (8K: 510, 4K: 135) -- config 5 115.0 -> 111.5 ms, config 3
+	// 24.05 -> 23.90; on a 1080p frame (40 super-tiles) the shares are too uneven: +8 % (profiles/r04_xcd_handout.txt)
+	int geo_xcd = (static_cast<long long>(geo_tiles_x) * geo_tiles_y >= 32000) ? 1 : 0;
+	if (tuning().xcd_handout == 0 || tuning().xcd_handout == 1) geo_xcd = tuning().xcd_handout;
+	// The hand-out counts tickets in 32 bits (trace.hip: `my_tickets`, `base + want`).  The busiest counter owns a 1/8 share of the
+	// units -- groups of four chunks, or 256x256-pixel super-tiles of 4096 chunks -- times 16 tickets per chunk and, with (chunk,
+	// sample) items, per sample; every wave may overshoot a used-up counter once by up to 64.
+	auto tickets_fit = [&](bool sample_items) {
+		const long long tiles = static_cast<long long>(geo_tiles_x) * geo_tiles_y;
+		const long long per_chunk = 16ll * (sample_items ? std::max(fp->spp, 1) : 1);
+		long long share;
+		if (geo_xcd) {
+			const long long st = static_cast<long long>((geo_tiles_x + 15) / 16) * ((geo_tiles_y + 15) / 16);
+			share = ((st + 7) / 8) * 4096ll * per_chunk;
+		} else {
+			share = ((tiles * 4 + 7) / 8) * 4ll * per_chunk;
+		}
+		return share < (1ll << 30) - (1ll << 24); // (2^30: the hand-out divides ticket numbers with 30-bit-exact multiply-high constants)
+	};
+	if (!tickets_fit((promoted.flags & BM_FLAG_SAMPLE_ITEMS) != 0)) { // what the caller asked for does not fit: refuse
+		set_error("frame too large for the 32-bit ticket counters: tiles x samples per launch (lower spp per call, or render row-band shards)");
+		return BM_EINVAL;
+	}
+	// (chunk, sample) items as the library's own choice -- only where their tickets fit; pixel items carry no spp factor and always
+	// do at this point (helper lanes work with either: atomic_acc = HELP)
+	if (!ordered && promoted.spp >= 2 && tickets_fit(true)) promoted.flags |= BM_FLAG_SAMPLE_ITEMS;
 	std::memset(fc, 0, sizeof *fc);
 	const V3 dir{cam->direction[0], cam->direction[1], cam->direction[2]};
 	const V3 upv{cam->up[0], cam->up[1], cam->up[2]};
@@ -128,24 +171,19 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_
 	fc->base_frame = fp->base_frame; fc->flags = fp->flags;
 	fc->band_rows = fp->band_rows; fc->shard_rank = fp->shard_rank; fc->shard_count = fp->shard_count;
 	fc->local_rows = bm_local_rows(fp);
-	fc->tiles_x = (fp->width + 15) / 16;
-	fc->tiles_y = (fc->local_rows + 15) / 16;
+	fc->tiles_x = geo_tiles_x;
+	fc->tiles_y = geo_tiles_y;
 	// When does a wave stop to refill?  Every refill costs the whole wave an atomic's round trip and ~110 instructions, every idle
 	// lane costs its share of all passes until then.  An item is all samples of a pixel (or ONE with BM_FLAG_SAMPLE_ITEMS): the
 	// longer it is, the rarer the refills, the earlier they pay (measured per workload, profiles/r04_refill_sweep.txt).
-	static const int refill_override = [] { const char* e = std::getenv("BM_REFILL_MIN"); return e ? std::atoi(e) : 0; }(); // tuning runs
+	const int refill_override = tuning().refill_min;
 	const int samples_per_item = (fp->flags & BM_FLAG_SAMPLE_ITEMS) ? 1 : fp->spp;
 	fc->refill_min = samples_per_item >= 4 ? 4 : (samples_per_item >= 2 ? 8 : 16);
-	// XCD-aware hand-out: neighbouring rays behind ONE L2 instead of all eight.  Pays where the scene does not fit the caches and the
-	// frame has enough 256x256-pixel super-tiles for eight even shares (8K: 510, 4K: 135) -- config 5 115.0 -> 111.5 ms, config 3
-	// 24.05 -> 23.90; on a 1080p frame (40 super-tiles) the shares are too uneven: +8 % (profiles/r04_xcd_handout.txt)
-	fc->xcd_handout = (static_cast<long long>(fc->tiles_x) * fc->tiles_y >= 32000) ? 1 : 0;
-	static const int xcd_override = [] { const char* e = std::getenv("BM_XCD_HANDOUT"); return e ? std::atoi(e) : -1; }(); // tuning runs / tests
-	if (xcd_override == 0 || xcd_override == 1) fc->xcd_handout = xcd_override;
+	fc->xcd_handout = geo_xcd;
 	if (refill_override >= 1 && refill_override <= 64) fc->refill_min = refill_override;
 	// shadow rays on helper lanes (trace.hip HELP): every frame that is not ordered (above)
 	fc->helpers = ordered ? 0 : 1;
-	static const int help_override = [] { const char* e = std::getenv("BM_HELPERS"); return e ? std::atoi(e) : -1; }();
+	const int help_override = tuning().helpers;
 	if (help_override == 0 || (help_override == 1 && !ordered)) fc->helpers = help_override;
 	// with helper lanes an idle lane is not wasted while it waits for the refill -- it takes shadow rays -- so the wave refills later:
 	// 24 idle lanes instead of 16 (config 2 -0.2 %, 1080p at 4 spp -1.1 %, config 3 -0.8 %; 32: worse again; profiles/r05_refill_sweep.txt)
@@ -156,24 +194,6 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_
 		set(static_cast<uint32_t>(fc->tiles_x), &fc->div_tiles_x_magic, &fc->div_tiles_x_shift);
 		set(static_cast<uint32_t>(fc->band_rows), &fc->div_band_magic, &fc->div_band_shift);
 		set(static_cast<uint32_t>((fc->tiles_x + 15) / 16), &fc->div_st_x_magic, &fc->div_st_x_shift);
-	}
-	// The hand-out counts tickets in 32 bits (trace.hip: `my_tickets`, `base + want`).  The busiest counter owns a 1/8 share of the
-	// units -- groups of four chunks, or 256x256-pixel super-tiles of 4096 chunks -- times 16 tickets per chunk and, with (chunk,
-	// sample) items, per sample; every wave may overshoot a used-up counter once by up to 64.  Refuse what would wrap.
-	{
-		const long long tiles = static_cast<long long>(fc->tiles_x) * fc->tiles_y;
-		const long long per_chunk = 16ll * ((fp->flags & BM_FLAG_SAMPLE_ITEMS) ? std::max(fp->spp, 1) : 1);
-		long long share;
-		if (fc->xcd_handout) {
-			const long long st = static_cast<long long>((fc->tiles_x + 15) / 16) * ((fc->tiles_y + 15) / 16);
-			share = ((st + 7) / 8) * 4096ll * per_chunk;
-		} else {
-			share = ((tiles * 4 + 7) / 8) * 4ll * per_chunk;
-		}
-		if (share >= (1ll << 30) - (1ll << 24)) { // (2^30: the hand-out divides ticket numbers with 30-bit-exact multiply-high constants)
-			set_error("frame too large for the 32-bit ticket counters: tiles x samples per launch (lower spp per call, or render row-band shards)");
-			return BM_EINVAL;
-		}
 	}
 	return 0;
 }
@@ -245,17 +265,15 @@ int Scene::init(int grid_size, int grid_height) {
 	}
 	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_counters_), sizeof(DeviceCounters)));
 	BM_HIP(hipMemset(d_counters_, 0, sizeof(DeviceCounters)));
-	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_work_counter_), kWorkCounterBytes * kTimingRing)); // one block of counters per launch in flight
-	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_frame_constants_), kTimingRing * sizeof(FrameConstants)));
-	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_frame_constants_), kTimingRing * sizeof(FrameConstants), hipHostMallocDefault));
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_work_counter_), kWorkCounterBytes * kFrameRing)); // one block of counters per frame in flight
+	BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_frame_constants_), kFrameRing * sizeof(FrameConstants)));
+	BM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_frame_constants_), kFrameRing * sizeof(FrameConstants), hipHostMallocDefault));
+	std::fill(ring_owner_, ring_owner_ + kFrameRing, -1ll);
 	hipDeviceProp_t prop;
 	BM_HIP(hipGetDeviceProperties(&prop, device_));
 	compute_units_ = prop.multiProcessorCount; // main.cpp:97 sm_cores
 	blocks_per_cu_[0] = blocks_per_cu_[1] = 0; // no cap: every instantiation of the fused kernel runs at its own occupancy (trace.hip launch_trace)
-	if (const char* cap = std::getenv("BM_TRACE_BLOCKS_PER_CU")) { // experiment knob: fewer resident waves per SIMD (1 block = 1 wave per SIMD)
-		const int n = std::atoi(cap);
-		if (n > 0) blocks_per_cu_[0] = n;
-	}
+	if (tuning().blocks_per_cu > 0) blocks_per_cu_[0] = tuning().blocks_per_cu; // experiment knob: fewer resident waves per SIMD (1 block = 1 wave per SIMD)
 
 	return alloc_queue();
 }
@@ -958,35 +976,97 @@ int Scene::device_brick(int supercell, uint32_t device_slot, uint32_t* out16) {
 
 // ---------------------------------------------------------------- frame launch (launch_kernels, kernel.cu:366-439)
 int Scene::render(const bm_camera* cam, const bm_frame_params* fp, float* accum, uint32_t* dbg, hipStream_t stream) {
+	return render_frames(1, cam, fp, &accum, dbg ? &dbg : nullptr, stream);
+}
+
+// `count` consecutive frames -- the reference's per-frame loop (main.cpp:117-147: one launch_kernels call per frame) -- as ONE launch
+// of the persistent kernel (trace.hip "FRAME RING"): frame i's constants, ticket counters and buffers are entry first + i of the
+// scene's rings, and every wave walks from frame to frame by itself.
+int Scene::render_frames(int count, const bm_camera* cams, const bm_frame_params* fps, float* const* accums, uint32_t* const* dbgs, hipStream_t stream) {
 	if (!on_device_) { set_error("scene not generated"); return BM_ESTATE; }
-	if (!accum) { set_error("null accumulation buffer"); return BM_EINVAL; }
-	FrameConstants fc;
-	if (int e = fill_frame_constants(cam, fp, &fc, dbg != nullptr)) return e;
+	if (count < 1 || count > kMaxFramesPerLaunch) { set_error("bm_render_frames: 1 ... 256 frames per launch"); return BM_EINVAL; }
+	if (!cams || !fps || !accums) { set_error("null argument"); return BM_EINVAL; }
+	bool hit_records = false;
+	for (int i = 0; i < count; ++i) {
+		if (!accums[i]) { set_error("null accumulation buffer"); return BM_EINVAL; }
+		hit_records = hit_records || (dbgs && dbgs[i]);
+	}
+	// ---- constants of every frame; what shapes the hand-out must be the same for all frames of a launch
+	std::vector<FrameConstants> fcs(static_cast<size_t>(count));
+	for (int i = 0; i < count; ++i) {
+		if (int e = fill_frame_constants(cams + i, fps + i, &fcs[static_cast<size_t>(i)], hit_records)) return e;
+		FrameConstants& f = fcs[static_cast<size_t>(i)];
+		f.accum = accums[i];
+		f.dbg = dbgs ? dbgs[i] : nullptr;
+		const FrameConstants& g = fcs[0];
+		if (f.width != g.width || f.height != g.height || f.spp != g.spp || f.max_bounces != g.max_bounces || f.flags != g.flags || f.band_rows != g.band_rows ||
+			f.shard_rank != g.shard_rank || f.shard_count != g.shard_count) {
+			set_error("bm_render_frames: the frames of one launch must agree in width, height, spp, max_bounces, flags and shard (camera, sun, sample_base, base_frame and buffers may differ)");
+			return BM_EINVAL;
+		}
+	}
+	const FrameConstants& fc = fcs[0];
+	if (count > 1) {
+		// Frames of a launch overlap in time.  Hit records are written with plain stores, and so are the pixels of frames that neither
+		// run helper lanes nor (chunk, sample) items (read when a lane takes the pixel, written back when it is done): such frames
+		// need buffers of their own.  Frames that add with float atomics may share one buffer, like consecutive frames of the
+		// reference's accumulation (kernel.cu:319-322,341-343).
+		const size_t pixels = static_cast<size_t>(fc.local_rows) * static_cast<size_t>(fc.width);
+		const bool plain_pixels = !(fc.helpers || (fc.flags & BM_FLAG_SAMPLE_ITEMS));
+		for (int i = 0; i < count; ++i)
+			for (int k = 0; k < i; ++k) {
+				const char *a = reinterpret_cast<const char*>(accums[i]), *b = reinterpret_cast<const char*>(accums[k]);
+				if (plain_pixels && a < b + pixels * 16 && b < a + pixels * 16) {
+					set_error("bm_render_frames: ordered frames of one launch need accumulation buffers of their own (they overlap in time and write pixels back with plain stores)");
+					return BM_EINVAL;
+				}
+				const char *c = dbgs ? reinterpret_cast<const char*>(dbgs[i]) : nullptr, *d = dbgs ? reinterpret_cast<const char*>(dbgs[k]) : nullptr;
+				if (c && d && c < d + pixels * 32 && d < c + pixels * 32) {
+					set_error("bm_render_frames: the frames of one launch need hit-record buffers of their own");
+					return BM_EINVAL;
+				}
+			}
+	}
 	BM_HIP(hipSetDevice(device_));
 	// `stream` is used as given: nullptr is HIP's default stream (what the reference's <<<>>> launches use), which is
 	// ordered with the caller's other default-stream work (e.g. torch's fill kernels on the accumulation buffer).
-	if (int e = frame_begin(stream)) return e; // bricks uploaded on the load stream must be visible to this frame
-	const bool instrumented = dbg != nullptr || (fp->flags & BM_FLAG_COUNTERS);
+	if (int e = frame_begin(stream)) return e; // bricks uploaded on the load stream must be visible to these frames
+	const bool instrumented = hit_records || (fc.flags & BM_FLAG_COUNTERS);
 	const int slot = static_cast<int>(launches_ % kTimingRing);
-	uint32_t* const work_counter = d_work_counter_ + static_cast<size_t>(slot) * (kWorkCounterBytes / sizeof(uint32_t)); // this launch's own block
-	BM_HIP(hipMemsetAsync(work_counter, 0, kWorkCounterBytes, stream)); // chunk counters of the persistent kernel
-	// the pinned slot (and its event pair) is reused every kTimingRing launches: make sure the launch that used it last has
-	// consumed it -- a caller that queues hundreds of frames without a sync would otherwise overwrite constants whose copy
-	// has not run yet (the event is almost always complete already, so this costs nothing)
+	// the event pair of this slot is reused every kTimingRing launches: wait for the launch that used it last (almost always done)
 	if (launches_ >= kTimingRing) BM_HIP(hipEventSynchronize(ev_stop_[slot]));
-	h_frame_constants_[slot] = fc;
-	BM_HIP(hipMemcpyAsync(d_frame_constants_ + slot, h_frame_constants_ + slot, sizeof(FrameConstants), hipMemcpyHostToDevice, stream));
+	// ---- `count` consecutive entries of the frame ring (constants + ticket counters).  An entry is free once the launch that used
+	// it last has finished: launches older than the timing ring have been waited for when their event pair was recycled (above, in
+	// their turn); a younger one is waited for here -- a caller that queues thousands of frames without a synchronisation would
+	// otherwise overwrite constants whose copy has not run yet.
+	int first = ring_next_;
+	if (first + count > kFrameRing) first = 0;
+	long long waited = -1;
+	for (int e = first; e < first + count; ++e) {
+		const long long owner = ring_owner_[e];
+		if (owner >= 0 && owner != waited && launches_ - owner < kTimingRing) {
+			BM_HIP(hipEventSynchronize(ev_stop_[owner % kTimingRing]));
+			waited = owner;
+		}
+	}
+	uint32_t* const work_counter = d_work_counter_ + static_cast<size_t>(first) * (kWorkCounterBytes / sizeof(uint32_t)); // one block per frame
+	BM_HIP(hipMemsetAsync(work_counter, 0, kWorkCounterBytes * static_cast<size_t>(count), stream)); // ticket counters of the persistent kernel
+	std::memcpy(h_frame_constants_ + first, fcs.data(), sizeof(FrameConstants) * static_cast<size_t>(count));
+	BM_HIP(hipMemcpyAsync(d_frame_constants_ + first, h_frame_constants_ + first, sizeof(FrameConstants) * static_cast<size_t>(count), hipMemcpyHostToDevice, stream));
 	BM_HIP(hipEventRecord(ev_start_[slot], stream));
 #ifdef BM_PHASE_TIMING
 	DeviceCounters* const counters_arg = d_counters_; // profiling build: the plain kernel reports its phase timers too
 #else
-	DeviceCounters* const counters_arg = (fp->flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr;
+	DeviceCounters* const counters_arg = (fc.flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr;
 #endif
-	launch_trace(view_, fc, d_frame_constants_ + slot, accum, dbg, counters_arg, work_counter, instrumented,
+	launch_trace(view_, fc, d_frame_constants_ + first, count, counters_arg, work_counter, instrumented,
 				 compute_units_, blocks_per_cu_[instrumented ? 1 : 0], stream);
 	BM_HIP(hipGetLastError());
 	BM_HIP(hipEventRecord(ev_stop_[slot], stream));
 	if (int e = frame_end(stream)) return e; // what process_load_queue orders itself behind
+	for (int e = first; e < first + count; ++e) ring_owner_[e] = launches_;
+	ring_next_ = first + count;
+	launch_frames_[slot] = count;
 	launches_++;
 	return 0;
 }

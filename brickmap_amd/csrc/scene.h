@@ -26,6 +26,12 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 void division_magic(uint32_t d, uint32_t* magic, int* shift); // floor(n / d) = umulhi(n, magic) >> shift for n < 2^30 (scene.cpp)
 
+// tuning overrides from the environment (scene.cpp tuning()): 0 / -1 = not set
+struct Tuning {
+	int refill_min = 0, xcd_handout = -1, helpers = -1, blocks_per_cu = 0;
+};
+const Tuning& tuning();
+
 class Scene {
 public:
 	explicit Scene(int device) : device_(device) {}
@@ -45,6 +51,8 @@ public:
 	int device_indices(int supercell, uint32_t* out4096);
 	int device_brick(int supercell, uint32_t device_slot, uint32_t* out16);
 	int render(const bm_camera* cam, const bm_frame_params* fp, float* accum, uint32_t* dbg, hipStream_t stream);
+	// `count` consecutive frames as one launch (the frame ring, trace.hip); dbgs may be null, and so may any of its entries
+	int render_frames(int count, const bm_camera* cams, const bm_frame_params* fps, float* const* accums, uint32_t* const* dbgs, hipStream_t stream);
 	int resolve(const float* accum, float* out, long long n, hipStream_t stream);
 	int synchronize();
 	int last_render_ms(float* ms);
@@ -115,9 +123,14 @@ private:
 	uint32_t* d_bricks_queue_ = nullptr;
 	uint32_t* d_indices_queue_ = nullptr;
 	DeviceCounters* d_counters_ = nullptr;
-	FrameConstants* d_frame_constants_ = nullptr; // kTimingRing device copies, one per in-flight launch
+	// the frame ring: constants and ticket counters of the frames in flight -- a launch takes as many consecutive entries as it has frames
+	static constexpr int kFrameRing = 1024, kMaxFramesPerLaunch = 256;
+	FrameConstants* d_frame_constants_ = nullptr; // kFrameRing device copies
 	FrameConstants* h_frame_constants_ = nullptr; // pinned source of the copies
-	uint32_t* d_work_counter_ = nullptr; // chunk counters of the persistent trace kernel: kTimingRing blocks, one per launch, zeroed before it
+	uint32_t* d_work_counter_ = nullptr; // chunk counters of the persistent trace kernel: kFrameRing blocks of kWorkCounterBytes, zeroed before the launch that uses them
+	long long ring_owner_[kFrameRing];   // the launch (value of launches_) that used the entry last, -1 = none
+	int ring_next_ = 0;
+	int launch_frames_[kTimingRing] = {}; // frames of the launch in each timing slot
 	int compute_units_ = 0, blocks_per_cu_[2] = {0, 0};
 	// pinned staging (Scene.cpp:30-32)
 	int* h_positions_[2] = {nullptr, nullptr};

@@ -11,6 +11,7 @@
 // Launch geometry: persistent 256-thread workgroups (compute units x resident blocks); waves pull rows of 4x4-pixel
 // chunks from interleaved ticket counters and schedule their lanes' work in phases (see trace_paths below).
 // The device functions shared with the queue-based schedule (wavefront.hip) live in traverse.h.
+#include "kernels.h"
 #include "traverse.h"
 
 namespace bm {
@@ -119,24 +120,38 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 // written back with atomics as well (the accumulator starts at zero in the lane), so radiance is equal up to summation order.
 template <bool DBG, bool XCD = false, bool HELP = false>
 // (the instrumented variant carries hit records and counters: it gets the registers instead of the occupancy)
-__global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, float4* __restrict__ accum,
-												  uint32_t* __restrict__ dbg, DeviceCounters* __restrict__ counters,
-												  uint32_t* __restrict__ work_counter) {
+__global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, int n_frames,
+												  DeviceCounters* __restrict__ counters, uint32_t* __restrict__ work_counter) {
 	// the per-frame constants live in device memory (not in the kernel-argument registers): they are read with scalar
 	// loads where they are needed, which keeps the scalar register file free for the scheduler loop
-	const FrameConstants& fc = *fcp;
+	//
+	// FRAME RING.  One launch traces `n_frames` consecutive frames (bm_render_frames; the reference's loop is one launch_kernels call
+	// per frame, main.cpp:117-147, kernel.cu:416-420): fcp[0 ... n_frames) are their constants -- camera, sun, sample_base, base_frame
+	// and the accumulation / hit-record buffers may differ from frame to frame; everything that shapes the hand-out (size, samples,
+	// flags, shard, max_bounces) is the same for all of them (Scene::render_frames checks) and is read through `fg` below -- and every
+	// frame has its own block of ticket counters behind `work_counter`.  A wave that finds the counters of its frame used up lets
+	// its lanes finish their paths and then moves on to the next frame BY ITSELF: the waves of a frame do not wait for one another,
+	// so the end of frame i -- the latency of the paths that started last, a sixth of a 1080p / 1-spp frame -- is covered by the
+	// beginning of frame i+1 instead of an idle GPU, whatever the runtime does with streams.  The constants stay wave-uniform:
+	// all lanes of a wave are always in the same frame.
+	const FrameConstants& fg = *fcp;     // what all frames of the launch share
+	const FrameConstants* fcq = fcp;     // the frame this wave is in
+#define fc (*fcq)
+	int frames_left = __builtin_amdgcn_readfirstlane(n_frames) - 1;
+	float4* __restrict__ accum = reinterpret_cast<float4*>(fc.accum);
+	uint32_t* __restrict__ dbg = fc.dbg;
 	__shared__ unsigned long long lds_brick[8 * 256]; // 16 KiB: one 64-byte brick per thread (traverse.h brick_dma_to_lds: word k of thread t at u32 word k * 256 + t)
 	const int lane = threadIdx.x & 63;
-	const uint32_t W = static_cast<uint32_t>(fc.width), H = static_cast<uint32_t>(fc.height);
-	const uint32_t total_chunks = static_cast<uint32_t>(fc.tiles_x) * static_cast<uint32_t>(fc.tiles_y) * 16u;
+	const uint32_t W = static_cast<uint32_t>(fg.width), H = static_cast<uint32_t>(fg.height);
+	const uint32_t total_chunks = static_cast<uint32_t>(fg.tiles_x) * static_cast<uint32_t>(fg.tiles_y) * 16u;
 	// Work items.  Default: a lane traces ALL samples of its pixel in order (fixed accumulation order per pixel, one plain
 	// write-back).  BM_FLAG_SAMPLE_ITEMS: the item is ONE sample of a 4x4 chunk -- spp times more, spp times shorter items,
 	// which keeps the persistent waves fed when a shard has few pixels and many samples (the 1/N row-band shards of a
 	// multi-GPU frame); samples of one pixel then run on different lanes and are added with float atomics like the
 	// reference does (kernel.cu:319-322,341-343), so radiance is equal up to summation order.
-	const bool sample_items = (fc.flags & 4u) != 0u; // BM_FLAG_SAMPLE_ITEMS
+	const bool sample_items = (fg.flags & 4u) != 0u; // BM_FLAG_SAMPLE_ITEMS
 	constexpr uint32_t kParts = 16u / BM_ITEM_LANES; // tickets per chunk and sample
-	const uint32_t items_per_chunk = (sample_items ? static_cast<uint32_t>(fc.spp > 0 ? fc.spp : 1) : 1u) * kParts;
+	const uint32_t items_per_chunk = (sample_items ? static_cast<uint32_t>(fg.spp > 0 ? fg.spp : 1) : 1u) * kParts;
 	const bool atomic_acc = HELP || sample_items; // other lanes may add to the pixel while this one holds it: add, never overwrite
 
 	// per-pixel state
@@ -189,16 +204,18 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	// on another XCD's counter traces the same pixels with worse locality; tests render the same frame under both hand-outs.)
 	constexpr uint32_t kXcdTiles = 16u, kStChunks = kXcdTiles * kXcdTiles * 16u;
 	constexpr bool xcd_handout = XCD;
-	int my_counter = xcd_handout ? static_cast<int>(blockIdx.x % kCounters)
-								 : static_cast<int>((blockIdx.x * 4u + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)))) % kCounters);
+	const int first_counter = xcd_handout ? static_cast<int>(blockIdx.x % kCounters)
+										  : static_cast<int>((blockIdx.x * 4u + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)))) % kCounters);
+	int my_counter = first_counter;
 	int counters_done = 0;
 	// hang guard only (NaN directions): no wave needs more scheduler rounds than this
-	const long long round_budget = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fc.spp) + 1) * (fc.max_bounces + 2) *
+	const long long round_budget = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fg.spp) + 1) * (fg.max_bounces + 2) *
 								   (2ll * sc.cells + sc.cells_height + 64);
 	// (64-bit products are computed by the vector unit: bring the count back into scalar registers, or every test of it
 	// turns the scheduler loop's branches into exec-mask branches)
-	long long rounds_left = static_cast<long long>((static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(round_budget >> 32)))) << 32) |
-												   static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(round_budget))));
+	const long long rounds_per_frame = static_cast<long long>((static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(round_budget >> 32)))) << 32) |
+															  static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(round_budget))));
+	long long rounds_left = rounds_per_frame;
 	uint32_t runsA = 0, lanesA = 0, runsB = 0, lanesB = 0, runsC = 0, lanesC = 0, runsD = 0, lanesD = 0, runsJ = 0, lanesJ = 0; // wave-uniform scheduler statistics
 
 	unsigned long long cycA = 0, cycB = 0, cycC = 0, cycD = 0;
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		// ---- refill: hand pixels to idle lanes, BM_ITEM_LANES at a time (consecutive tickets walk through a 4x4 chunk)
 		const unsigned long long idle = __ballot(state == ST_IDLE);
 		const int nI = __popcll(idle);
-		if (work_left && nI >= fc.refill_min) {
+		if (work_left && nI >= fg.refill_min) {
 			// One global word serves only ~90 returning atomics per microsecond chip-wide, and a refill stalls the whole
 			// wave until its atomic returns; with thousands of waves on one counter that queue is tens of microseconds
 			// long.  The chunk sequence is therefore dealt to kCounters interleaved counters (8x8-pixel groups of four
@@ -227,7 +244,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			if (lane == 0) base = atomicAdd(work_counter + my_counter * kCounterStride, static_cast<uint32_t>(want));
 			base = __builtin_amdgcn_readfirstlane(base);
 			// units dealt to the counters: groups of four chunks, or whole super-tiles
-			const uint32_t st_x = (static_cast<uint32_t>(fc.tiles_x) + kXcdTiles - 1u) / kXcdTiles, st_y = (static_cast<uint32_t>(fc.tiles_y) + kXcdTiles - 1u) / kXcdTiles;
+			const uint32_t st_x = (static_cast<uint32_t>(fg.tiles_x) + kXcdTiles - 1u) / kXcdTiles, st_y = (static_cast<uint32_t>(fg.tiles_y) + kXcdTiles - 1u) / kXcdTiles;
 			const uint32_t total_units = xcd_handout ? st_x * st_y : (total_chunks + 3u) >> 2;
 			const uint32_t my_units = total_units > static_cast<uint32_t>(my_counter)
 										  ? (total_units - static_cast<uint32_t>(my_counter) + kCounters - 1u) / kCounters : 0u;
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 				const uint32_t item = base + static_cast<uint32_t>(rank / BM_ITEM_LANES);
 				// items_per_chunk = samples x kParts: divide by the power of two first, then by the samples (a prepared constant)
 				static_assert((kParts & (kParts - 1u)) == 0u, "kParts is a power of two");
-				const uint32_t ticket = div_const(item / kParts, fc.div_samples_magic, fc.div_samples_shift), item_sub = item - ticket * items_per_chunk;
+				const uint32_t ticket = div_const(item / kParts, fg.div_samples_magic, fg.div_samples_shift), item_sub = item - ticket * items_per_chunk;
 				const uint32_t item_sample = item_sub / kParts, part = item_sub % kParts; // (kParts == 1: part 0)
 				uint32_t k;
 				int tile_x, tile_y;
@@ -251,16 +268,16 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					const uint32_t st = (ticket / kStChunks) * kCounters + counter_now, in_st = ticket % kStChunks;
 					const uint32_t tw = in_st >> 4;
 					k = in_st & 15u;
-					const uint32_t st_row = div_const(st, fc.div_st_x_magic, fc.div_st_x_shift);
+					const uint32_t st_row = div_const(st, fg.div_st_x_magic, fg.div_st_x_shift);
 					tile_x = static_cast<int>((st - st_row * st_x) * kXcdTiles + tw % kXcdTiles);
 					tile_y = static_cast<int>(st_row * kXcdTiles + tw / kXcdTiles);
-					in_frame = tile_x < fc.tiles_x && tile_y < fc.tiles_y;
+					in_frame = tile_x < fg.tiles_x && tile_y < fg.tiles_y;
 				} else {
 					const uint32_t chunk = ((ticket >> 2) * kCounters + counter_now) * 4u + (ticket & 3u);
 					const uint32_t tile = chunk >> 4;
 					k = chunk & 15u;
-					tile_y = static_cast<int>(div_const(tile, fc.div_tiles_x_magic, fc.div_tiles_x_shift));
-					tile_x = static_cast<int>(tile - static_cast<uint32_t>(tile_y) * static_cast<uint32_t>(fc.tiles_x));
+					tile_y = static_cast<int>(div_const(tile, fg.div_tiles_x_magic, fg.div_tiles_x_shift));
+					tile_x = static_cast<int>(tile - static_cast<uint32_t>(tile_y) * static_cast<uint32_t>(fg.tiles_x));
 					in_frame = chunk < total_chunks;
 				}
 				if (item < my_tickets && in_frame) {
@@ -268,14 +285,14 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					const uint32_t q = part * BM_ITEM_LANES + (static_cast<uint32_t>(rank) % BM_ITEM_LANES); // pixel of the 4x4 chunk
 					const int x = tile_x * 16 + cx * 4 + static_cast<int>(q & 3u);
 					const int ly = tile_y * 16 + cy * 4 + static_cast<int>(q >> 2); // row inside this shard's packed buffer
-					const int band = static_cast<int>(div_const(static_cast<uint32_t>(ly), fc.div_band_magic, fc.div_band_shift)); // ly / band_rows
-					const int y = (band * fc.shard_count + fc.shard_rank) * fc.band_rows + (ly - band * fc.band_rows);
-					if (x < fc.width && ly < fc.local_rows && y < fc.height) {
+					const int band = static_cast<int>(div_const(static_cast<uint32_t>(ly), fg.div_band_magic, fg.div_band_shift)); // ly / band_rows
+					const int y = (band * fg.shard_count + fg.shard_rank) * fg.band_rows + (ly - band * fg.band_rows);
+					if (x < fg.width && ly < fg.local_rows && y < fg.height) {
 						p = static_cast<uint32_t>(y) * W + static_cast<uint32_t>(x);
 						local_pixel = static_cast<uint32_t>(ly) * W + static_cast<uint32_t>(x);
 						xy = static_cast<uint32_t>(x) | (static_cast<uint32_t>(y) << 16);
 						s = sample_items ? static_cast<int>(item_sample) : 0;
-						s_end = sample_items ? s + 1 : fc.spp;
+						s_end = sample_items ? s + 1 : fg.spp;
 						pstate = P_GEN;
 						state = ST_NEED;
 						if (!HELP) acc = atomic_acc ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[local_pixel];
@@ -294,7 +311,22 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		const int nC = __popcll(__ballot(state == ST_NEED) | __ballot(state == ST_CONN)); // shade / generate, and connect (same pass)
 		const int live = nA + nB + nC;
 		--rounds_left;
-		if (rounds_left < 0 || (live == 0 && !work_left)) break;
+		if (rounds_left < 0 || (live == 0 && !work_left)) {
+			// this wave has nothing left to do in its frame: on to the next frame of the launch (its constants, its buffers, its
+			// own ticket counters), or out.  Every lane is idle here, helpers included, so nothing of the old frame is in flight
+			// in this wave; other waves may still be tracing it.
+			if (rounds_left < 0 || frames_left <= 0) break;
+			--frames_left;
+			++fcq;
+			accum = reinterpret_cast<float4*>(fc.accum);
+			dbg = fc.dbg;
+			work_counter += kWorkCounterBytes / sizeof(uint32_t);
+			my_counter = first_counter;
+			counters_done = 0;
+			work_left = true;
+			rounds_left = rounds_per_frame;
+			continue;
+		}
 		// (live == 0 with chunks left: only pixels outside the image were handed out; the passes below find nothing to do)
 		// Policy: an expensive phase runs once a quarter of the live lanes wait for it, the cheap connect phase
 		// once an eighth does; otherwise the DDA keeps moving.  With no lane left in the DDA the largest group runs.
@@ -380,7 +412,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 							hseg = hmix(hseg, static_cast<uint32_t>(info.sub_id));
 						}
 					}
-					const bool primary_only = fc.flags & 1u; // BM_FLAG_PRIMARY_ONLY
+					const bool primary_only = fg.flags & 1u; // BM_FLAG_PRIMARY_ONLY
 					// direction whose sky terms are needed: the ray itself on a miss, the sun sample on a hit
 					f3 view = r.d; // RayQueue::direction of the extend ray that just finished
 					f3 miss_color = mk(0.f, 0.f, 0.f);
@@ -397,7 +429,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						view = cone_sample(fc, sseed);
 						sunLight = dot(pn, view);
 						cast = sunLight > 0.f;
-						terminated = !(bounces < fc.max_bounces);
+						terminated = !(bounces < fg.max_bounces);
 						if (terminated) {
 							add_terminated(); // kernel.cu:301
 						} else {
@@ -630,6 +662,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		for (int k = 0; k < 8; ++k) atomicAdd(&counters->detail[k], det[k]);
 	}
 }
+#undef fc
 
 // upload kernel (kernel.cu:141-151): scatter staged bricks into the arena and publish their index words
 __global__ void upload_bricks(const DeviceScene sc, const uint32_t* __restrict__ bricks_queue, const uint32_t* __restrict__ indices_queue,
@@ -715,8 +748,9 @@ int trace_blocks_per_cu(bool instrumented, bool xcd, bool help) {
 }
 
 // Persistent launch: exactly as many 256-thread workgroups as the device keeps resident (compute_units x
-// blocks per CU); the waves pull 4x4-pixel chunks from *work_counter, which must be zero at launch.
-void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameConstants* fc_dev, float* accum, uint32_t* dbg, DeviceCounters* counters,
+// blocks per CU); the waves pull 4x4-pixel chunks from the ticket counters behind work_counter -- one block of kWorkCounterBytes
+// per frame of the launch, all zero at launch.  fc = the host copy of the first frame's constants (fc_dev[0]).
+void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameConstants* fc_dev, int n_frames, DeviceCounters* counters,
 				  uint32_t* work_counter, bool instrumented, int compute_units, int blocks_per_cu_cap, hipStream_t stream) {
 	const long long chunks = static_cast<long long>(fc.tiles_x) * fc.tiles_y * 16;
 	if (chunks <= 0) return;
@@ -726,7 +760,6 @@ void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameCo
 	const long long resident_blocks = static_cast<long long>(compute_units) * per_cu;
 	long long blocks = (chunks + 15) / 16; // never more workgroups than 64-pixel groups
 	if (blocks > resident_blocks) blocks = resident_blocks;
-	float4* const acc4 = reinterpret_cast<float4*>(accum);
 	const dim3 grid(static_cast<unsigned>(blocks)), block(256);
 #ifdef BM_PHASE_TIMING
 	DeviceCounters* const plain_counters = counters; // profiling build: the plain kernel reports its phase timers too
@@ -734,13 +767,13 @@ void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameCo
 	DeviceCounters* const plain_counters = nullptr;
 #endif
 	const bool help = fc.helpers != 0;
-#define BM_LAUNCH_TRACE(D, X, H, DBGBUF, CNT) hipLaunchKernelGGL((trace_paths<D, X, H>), grid, block, 0, stream, sc, fc_dev, acc4, DBGBUF, CNT, work_counter)
+#define BM_LAUNCH_TRACE(D, X, H, CNT) hipLaunchKernelGGL((trace_paths<D, X, H>), grid, block, 0, stream, sc, fc_dev, n_frames, CNT, work_counter)
 	if (instrumented) {
-		if (xcd) { if (help) BM_LAUNCH_TRACE(true, true, true, dbg, counters); else BM_LAUNCH_TRACE(true, true, false, dbg, counters); }
-		else { if (help) BM_LAUNCH_TRACE(true, false, true, dbg, counters); else BM_LAUNCH_TRACE(true, false, false, dbg, counters); }
+		if (xcd) { if (help) BM_LAUNCH_TRACE(true, true, true, counters); else BM_LAUNCH_TRACE(true, true, false, counters); }
+		else { if (help) BM_LAUNCH_TRACE(true, false, true, counters); else BM_LAUNCH_TRACE(true, false, false, counters); }
 	} else {
-		if (xcd) { if (help) BM_LAUNCH_TRACE(false, true, true, nullptr, plain_counters); else BM_LAUNCH_TRACE(false, true, false, nullptr, plain_counters); }
-		else { if (help) BM_LAUNCH_TRACE(false, false, true, nullptr, plain_counters); else BM_LAUNCH_TRACE(false, false, false, nullptr, plain_counters); }
+		if (xcd) { if (help) BM_LAUNCH_TRACE(false, true, true, plain_counters); else BM_LAUNCH_TRACE(false, true, false, plain_counters); }
+		else { if (help) BM_LAUNCH_TRACE(false, false, true, plain_counters); else BM_LAUNCH_TRACE(false, false, false, plain_counters); }
 	}
 #undef BM_LAUNCH_TRACE
 }

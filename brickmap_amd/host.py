@@ -110,6 +110,29 @@ def local_rows(params: FrameParams) -> int:
     return int(_lib.load().bm_local_rows(C.byref(p)))
 
 
+def frame_plan(params: FrameParams, hit_records=False):
+    """bm_frame_plan_of: what the library decides for a frame with these parameters (host only): flags after its own choice of work
+    items, ordered / helpers / sample_items / xcd_handout / refill_min / instrumented, tiles and local rows."""
+    plan = _lib.bm_frame_plan()
+    par_c = params.to_c()
+    check(_lib.load().bm_frame_plan_of(C.byref(par_c), 1 if hit_records else 0, C.byref(plan)))
+    return {name: int(getattr(plan, name)) for name, _ in _lib.bm_frame_plan._fields_}
+
+
+def trace_waves_per_simd(instrumented=False, xcd_handout=False, helpers=True, device=0):
+    """bm_trace_waves_per_simd: resident waves per SIMD of the trace_paths instantiation on `device`."""
+    n = C.c_int(0)
+    check(_lib.load().bm_trace_waves_per_simd(device, int(bool(instrumented)), int(bool(xcd_handout)), int(bool(helpers)), C.byref(n)))
+    return int(n.value)
+
+
+def tuning_overrides():
+    """bm_tuning_overrides: {name: value} of the BM_* tuning variables this process runs under ({} = the product's own rules)."""
+    buf = C.create_string_buffer(512)
+    check(_lib.load().bm_tuning_overrides(buf, 512))
+    return {k: int(v) for k, v in (item.split("=") for item in buf.value.decode().split())}
+
+
 def host_cube_field(grid_size, grid_height):
     """The octant cube field of the generated world (bm_host_cube_field): uint8 [8, cells_height+2, cells+2, cells+2]."""
     L = _lib.load()
@@ -301,6 +324,34 @@ class Scene:
         cam_c, par_c = camera.to_c(), params.to_c()
         check(self._L.bm_render_frame(self.gpuScene, C.byref(cam_c), C.byref(par_c), C.c_void_p(accum.data_ptr()), dbg_ptr,
                                       C.c_void_p(stream)))
+
+    def render_frames(self, cameras, params, accums, debugs=None, stream=None):
+        """bm_render_frames: `len(params)` consecutive frames -- the reference's per-frame loop, main.cpp:117-147 -- as ONE launch (the
+        frame ring: every wave walks from a used-up frame to the next by itself).  cameras: one Camera for all frames or one per frame;
+        accums: one tensor for all frames (production frames add with float atomics) or one per frame; debugs: None or one entry per frame
+        (None or a hit-record tensor of its own)."""
+        import torch
+        n = len(params)
+        cams = list(cameras) if isinstance(cameras, (list, tuple)) else [cameras] * n
+        accs = list(accums) if isinstance(accums, (list, tuple)) else [accums] * n
+        dbgs = list(debugs) if debugs is not None else None
+        assert len(cams) == n and len(accs) == n and (dbgs is None or len(dbgs) == n)
+        cam_c = (_lib.bm_camera * n)(*[c.to_c() for c in cams])
+        par_c = (_lib.bm_frame_params * n)(*[p.to_c() for p in params])
+        acc_p = (C.c_void_p * n)()
+        dbg_p = (C.c_void_p * n)() if dbgs is not None else None
+        for i in range(n):
+            rows = local_rows(params[i])
+            a = accs[i]
+            assert a.is_cuda and a.dtype == torch.float32 and a.is_contiguous() and a.numel() == rows * params[i].width * 4, "accum must be [local_rows, width, 4]"
+            acc_p[i] = a.data_ptr()
+            if dbgs is not None and dbgs[i] is not None:
+                d = dbgs[i]
+                assert d.is_cuda and d.dtype == torch.int32 and d.is_contiguous() and d.numel() == rows * params[i].width * 8
+                dbg_p[i] = d.data_ptr()
+        if stream is None:
+            stream = torch.cuda.current_stream(accs[0].device).cuda_stream
+        check(self._L.bm_render_frames(self.gpuScene, n, cam_c, par_c, acc_p, dbg_p, C.c_void_p(stream)))
 
     def resolve(self, accum, out=None, stream=None):
         """blit_onto_framebuffer (kernel.cu:348-364) into an offscreen float4 tensor."""

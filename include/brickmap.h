@@ -211,12 +211,49 @@ BM_API int bm_local_rows(const bm_frame_params* params);
  * Frames of one scene that accumulate into the SAME buffer may overlap in time (issued on different streams) only
  * with BM_FLAG_SAMPLE_ITEMS, which adds samples with float atomics; without it a pixel is read when a lane takes it
  * and written back when it is done, so such frames must be ordered (one stream, or events).  Every launch has its
- * own ticket counters and constants (a ring of 256 launches in flight).  Scenes that stream bricks may have frames on
+ * own ticket counters and constants (a ring of 1024 frames / 256 launches in flight).  Scenes that stream bricks may have frames on
  * several streams as well: every stream is ordered behind the brick uploads it has not seen, and
  * bm_scene_process_load_queue orders itself behind the frames of all of them.  Width and height are limited to 65535, a
  * shard to 2^32 pixels. */
 BM_API int bm_render_frame(bm_scene* scene, const bm_camera* camera, const bm_frame_params* params,
                            float* accum_dev, uint32_t* debug_dev, void* hip_stream);
+/* The reference's frame loop -- launch_kernels once per frame, main.cpp:117-147 / kernel.cu:416-420 -- for `count` (1 ... 256)
+ * consecutive frames as ONE launch of the persistent kernel (the "frame ring", csrc/trace.hip): frame i is exactly
+ * bm_render_frame(scene, &cameras[i], &params[i], accum_dev[i], debug_dev ? debug_dev[i] : NULL), but a wave that finds frame i's
+ * ticket counters used up finishes its own paths and starts on frame i+1 by itself, so the end of a frame -- the latency of the
+ * paths that started last, a sixth of a 1080p / 1-spp frame -- is covered by the beginning of the next one instead of an idle GPU
+ * (1080p / 1 spp: 1.01 ms per frame as single launches, see DESIGN.md 4.6 for the ring).  Camera, sun_position, sample_base,
+ * base_frame and the buffers may differ from frame to frame; width, height, spp, max_bounces, flags and the shard must be the
+ * same (BM_EINVAL otherwise).  Frames of a launch OVERLAP in time: ordered frames (BM_FLAG_ORDERED, hit records, primary-only)
+ * write pixels back with plain stores and need accumulation buffers of their own; production frames add with float atomics
+ * and may share one buffer, like consecutive frames of the reference's accumulation.  debug_dev: NULL, or `count` entries, each
+ * NULL or a hit-record buffer of its own.  Results of ordered frames are bit-identical to `count` single launches.  Bricks
+ * requested by any frame of the launch are serviced by the next bm_scene_process_load_queue.  bm_render_times /
+ * bm_last_render_ms report the launch as one duration. */
+BM_API int bm_render_frames(bm_scene* scene, int count, const bm_camera* cameras, const bm_frame_params* params,
+                            float* const* accum_dev, uint32_t* const* debug_dev, void* hip_stream);
+
+/* What the library decides for a frame with these parameters (host only, no device needed): the flags after its own choice of
+ * work items, whether the frame is ordered, runs helper lanes, takes the XCD-aware hand-out, and when its waves refill.
+ * hit_records: the frame will be given a debug_dev buffer. */
+typedef struct bm_frame_plan {
+	uint32_t flags;        /* params->flags, plus BM_FLAG_SAMPLE_ITEMS where the library schedules (chunk, sample) items by itself */
+	int32_t ordered;       /* 1: one lane accumulates a pixel's events in path order (reproducible sums)                          */
+	int32_t helpers;       /* 1: shadow rays on helper lanes, float-atomic adds (csrc/trace.hip HELP)                             */
+	int32_t sample_items;  /* 1: (4x4 chunk, sample) work items                                                                  */
+	int32_t xcd_handout;   /* 1: 256x256-pixel super-tiles dealt to the eight XCDs' ticket counters (big frames)                 */
+	int32_t refill_min;    /* a wave takes new work items once this many of its lanes are idle                                    */
+	int32_t instrumented;  /* 1: the instrumented instantiation (hit records / BM_FLAG_COUNTERS) runs                             */
+	int32_t tiles_x, tiles_y, local_rows;
+} bm_frame_plan;
+BM_API int bm_frame_plan_of(const bm_frame_params* params, int hit_records, bm_frame_plan* out);
+/* resident waves per SIMD of the trace_paths instantiation <instrumented, xcd_handout, helpers> on `device` (what the register
+ * budget allows: hipOccupancyMaxActiveBlocksPerMultiprocessor of the 256-thread workgroup = one wave per SIMD each) */
+BM_API int bm_trace_waves_per_simd(int device, int instrumented, int xcd_handout, int helpers, int* waves);
+/* The tuning overrides this process runs under, as "NAME=value NAME=value" ("" when none is set): BM_REFILL_MIN,
+ * BM_XCD_HANDOUT, BM_HELPERS, BM_TRACE_BLOCKS_PER_CU -- A/B knobs read from the environment once; a measurement should echo them. */
+BM_API int bm_tuning_overrides(char* buf, size_t buflen);
+
 /* blit_onto_framebuffer (kernel.cu:348-364) into an offscreen float4 buffer: rgb/a, a=1, gamma 1/2.2 */
 BM_API int bm_resolve(bm_scene* scene, const float* accum_dev, float* out_dev, int64_t n_pixels, void* hip_stream);
 /* cudaDeviceSynchronize of launch_kernels:431 */
