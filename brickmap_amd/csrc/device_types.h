@@ -84,9 +84,12 @@ struct FrameConstants {
 	int div_samples_shift, div_tiles_x_shift, div_band_shift, div_st_x_shift;
 	int helpers;          // 1: shadow rays may be traced by idle lanes of the wave and added with float atomics (trace.hip HELP); 0: every pixel's events
 	                      // are accumulated in path order by the one lane that owns it (BM_FLAG_ORDERED, and every frame that writes hit records)
-	// where this frame's results go (trace.hip reads them per frame of a launch -- the frame ring; the queue kernels of wavefront.hip take theirs as arguments)
-	float* accum;         // float4 per pixel of the shard
-	uint32_t* dbg;        // hit records, 8 words per pixel, or null
+	// the frame ring (trace.hip): where this frame's results go, and how many frames of the launch follow it (the queue kernels of
+	// wavefront.hip take their buffers as arguments)
+	float* accum;          // float4 per pixel of the shard
+	uint32_t* dbg;         // hit records, 8 words per pixel, or null
+	int frames_after;      // 0: the launch's last frame
+	int reserved_;
 };
 
 struct DeviceCounters { // v: same order as bm_counters; sched: same order as bm_sched_stats

@@ -6,11 +6,11 @@
 
 namespace bm {
 constexpr size_t kWorkCounterBytes = 64 * 32 * sizeof(uint32_t); // up to 64 chunk counters, one 128-byte line each
-int trace_blocks_per_cu(bool instrumented, bool xcd_handout, bool helpers); // resident workgroups per CU of that instantiation
+int trace_blocks_per_cu(bool instrumented, bool xcd_handout, bool helpers, bool ring = false); // resident workgroups per CU of that instantiation (ring: a launch of several frames)
 // blocks_per_cu_cap: 0 = as many workgroups per CU as the instantiation keeps resident; > 0 = at most that many (tuning runs)
-// n_frames: frames of this launch (the frame ring, trace.hip): fc_dev[0 ... n_frames) are their constants -- each names its own accumulation / hit-record
-// buffers -- and work_counter is the first of n_frames zeroed blocks of kWorkCounterBytes; fc = host copy of fc_dev[0]
-void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameConstants* fc_dev, int n_frames, DeviceCounters* counters,
+// fc_dev[0], fc_dev[1], ... are the constants of the frames of this launch (the frame ring, trace.hip; the last entry has frames_after == 0): each
+// names its own accumulation / hit-record buffers; work_counter is the first of as many zeroed blocks of kWorkCounterBytes; fc = host copy of fc_dev[0]
+void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameConstants* fc_dev, DeviceCounters* counters,
 				  uint32_t* work_counter, bool instrumented, int compute_units, int blocks_per_cu_cap, hipStream_t stream);
 void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const uint32_t* indices_queue, uint32_t* arena, uint32_t count,
 				   hipStream_t stream);

@@ -998,6 +998,7 @@ int Scene::render_frames(int count, const bm_camera* cams, const bm_frame_params
 		FrameConstants& f = fcs[static_cast<size_t>(i)];
 		f.accum = accums[i];
 		f.dbg = dbgs ? dbgs[i] : nullptr;
+		f.frames_after = count - 1 - i;
 		const FrameConstants& g = fcs[0];
 		if (f.width != g.width || f.height != g.height || f.spp != g.spp || f.max_bounces != g.max_bounces || f.flags != g.flags || f.band_rows != g.band_rows ||
 			f.shard_rank != g.shard_rank || f.shard_count != g.shard_count) {
@@ -1059,7 +1060,7 @@ int Scene::render_frames(int count, const bm_camera* cams, const bm_frame_params
 #else
 	DeviceCounters* const counters_arg = (fc.flags & BM_FLAG_COUNTERS) ? d_counters_ : nullptr;
 #endif
-	launch_trace(view_, fc, d_frame_constants_ + first, count, counters_arg, work_counter, instrumented,
+	launch_trace(view_, fc, d_frame_constants_ + first, counters_arg, work_counter, instrumented,
 				 compute_units_, blocks_per_cu_[instrumented ? 1 : 0], stream);
 	BM_HIP(hipGetLastError());
 	BM_HIP(hipEventRecord(ev_stop_[slot], stream));

@@ -11,6 +11,8 @@
 // Launch geometry: persistent 256-thread workgroups (compute units x resident blocks); waves pull rows of 4x4-pixel
 // chunks from interleaved ticket counters and schedule their lanes' work in phases (see trace_paths below).
 // The device functions shared with the queue-based schedule (wavefront.hip) live in traverse.h.
+#include <type_traits>
+
 #include "kernels.h"
 #include "traverse.h"
 
@@ -40,6 +42,24 @@ namespace bm {
 // floor(n / d) for a per-frame constant d whose multiply-high constants the host prepared (FrameConstants::div_*; magic == 0: d == 1);
 // n < 2^30.  Three instructions instead of the ~17 of a 32-bit division by a run-time value.
 __device__ __forceinline__ uint32_t div_const(uint32_t n, uint32_t magic, int shift) { return magic ? (__umulhi(n, magic) >> shift) : n; }
+
+// The buffers of a frame are named by its constants (the frame ring), i.e. by pointers READ FROM MEMORY: generic pointers to the
+// compiler (flat_* instructions) unless an access says that it goes to global memory.
+typedef float bm_v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) bm_v4f v4f_in_global_memory;
+typedef __attribute__((address_space(1))) uint32_t u32_in_global_memory;
+__device__ __forceinline__ float4 pixel_load(const float4* p) { const bm_v4f v = *(const v4f_in_global_memory*)p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void pixel_store(float4* p, float4 v) { const bm_v4f w = {v.x, v.y, v.z, v.w}; *(v4f_in_global_memory*)p = w; }
+__device__ __forceinline__ void record_atomic_add(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_add((u32_in_global_memory*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The reference's atomicAdd on the accumulation buffer (kernel.cu:319-322,341-343), for a buffer whose address was READ FROM MEMORY
+// (the frame ring's constants): to the compiler such a pointer is generic and the add becomes flat_atomic_add_f32; the pixel
+// records live in global memory, and saying so gives global_atomic_add_f32 as with a kernel-argument pointer (same relaxed,
+// device-scope, result-unused read-modify-write as hip's unsafeAtomicAdd).
+__device__ __forceinline__ void pixel_atomic_add(float* p, float v) {
+	typedef __attribute__((address_space(1))) float float_in_global_memory;
+	[[clang::atomic(ignore_denormal_mode)]] { (void)__hip_atomic_fetch_add((float_in_global_memory*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
 
 enum : int { P_GEN = 0, P_EXT_DONE = 1, P_SHD_DONE = 2, P_BOUNCE = 3, P_HELPER = 6 };
 enum : int { ST_IDLE = 4, ST_CONN = 5 };
@@ -118,28 +138,39 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 // (kernel.cu:341-343).  The rays traced are the same rays; what changes is who walks them: idle lanes do useful work without a
 // refill, and a path's latency -- which is what the end of a frame waits for -- is its extend rays' alone.  Pixels are therefore
 // written back with atomics as well (the accumulator starts at zero in the lane), so radiance is equal up to summation order.
-template <bool DBG, bool XCD = false, bool HELP = false>
+// RING: the launch may hold more than one frame (the frame ring, below).  An instantiation of its own because the scheduler loop runs
+// at the limit of the scalar register file: the ring's one extra loop-carried scalar and the indexed constants cost a single-frame
+// launch 2.6 % (config 2 1.005 -> 1.031 ms, config 3 19.8 -> 20.4; four more spilled scalars in the hot loop), which a launch of
+// ONE frame has no reason to pay.
+template <bool DBG, bool XCD = false, bool HELP = false, bool RING = false>
 // (the instrumented variant carries hit records and counters: it gets the registers instead of the occupancy)
-__global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp, int n_frames,
+__global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp,
 												  DeviceCounters* __restrict__ counters, uint32_t* __restrict__ work_counter) {
 	// the per-frame constants live in device memory (not in the kernel-argument registers): they are read with scalar
 	// loads where they are needed, which keeps the scalar register file free for the scheduler loop
 	//
-	// FRAME RING.  One launch traces `n_frames` consecutive frames (bm_render_frames; the reference's loop is one launch_kernels call
-	// per frame, main.cpp:117-147, kernel.cu:416-420): fcp[0 ... n_frames) are their constants -- camera, sun, sample_base, base_frame
-	// and the accumulation / hit-record buffers may differ from frame to frame; everything that shapes the hand-out (size, samples,
-	// flags, shard, max_bounces) is the same for all of them (Scene::render_frames checks) and is read through `fg` below -- and every
-	// frame has its own block of ticket counters behind `work_counter`.  A wave that finds the counters of its frame used up lets
-	// its lanes finish their paths and then moves on to the next frame BY ITSELF: the waves of a frame do not wait for one another,
-	// so the end of frame i -- the latency of the paths that started last, a sixth of a 1080p / 1-spp frame -- is covered by the
-	// beginning of frame i+1 instead of an idle GPU, whatever the runtime does with streams.  The constants stay wave-uniform:
-	// all lanes of a wave are always in the same frame.
+	// FRAME RING.  One launch traces one or more consecutive frames (bm_render_frames; the reference's loop is one launch_kernels call
+	// per frame, main.cpp:117-147, kernel.cu:416-420): fcp[0], fcp[1], ... are their constants (FrameConstants::frames_after of the
+	// last one is 0) -- camera, sun, sample_base, base_frame and the accumulation / hit-record buffers may differ from frame to
+	// frame; everything that shapes the hand-out (size, samples, flags, shard, max_bounces) is the same for all of them
+	// (Scene::render_frames checks) and is read through `fg` below -- and every frame has its own block of ticket counters behind
+	// `work_counter`.  A wave that finds the counters of its frame used up lets its lanes finish their paths and then moves on to
+	// the next frame BY ITSELF: the waves of a frame do not wait for one another, so the end of frame i -- the latency of the
+	// paths that started last, a sixth of a 1080p / 1-spp frame -- is covered by the beginning of frame i+1 instead of an idle GPU,
+	// whatever the runtime does with streams.  The constants stay wave-uniform: all lanes of a wave are always in the same frame.
+	//
+	// What the ring may cost a single frame is scalar registers -- the scheduler loop runs at the limit of the scalar file, and every
+	// value carried round it for the ring's sake is a spill (v_readlane / v_writelane in the hot loop: the first version, with the
+	// frame count, the first frame's buffers and the per-frame round budget as live scalars, was 4 % slower on every workload).  So
+	// the loop carries ONE extra scalar, the frame's index: the buffers are read from the frame's constants when a wave enters it,
+	// "is this the last frame" is a field of the constants read when a wave has run dry, and what a frame start needs (first ticket
+	// counter, round budget) is recomputed there.  The frame is an INDEX into the `__restrict__` array, never a pointer carried
+	// round the loop: only then does the compiler prove that the kernel's stores leave the constants alone (scalar loads).
 	const FrameConstants& fg = *fcp;     // what all frames of the launch share
-	const FrameConstants* fcq = fcp;     // the frame this wave is in
-#define fc (*fcq)
-	int frames_left = __builtin_amdgcn_readfirstlane(n_frames) - 1;
-	float4* __restrict__ accum = reinterpret_cast<float4*>(fc.accum);
-	uint32_t* __restrict__ dbg = fc.dbg;
+	int ring_pos = 0;                    // the frame of the launch this wave is in (RING; otherwise the constant 0)
+#define fc (fcp[RING ? ring_pos : 0])
+	float4* accum = reinterpret_cast<float4*>(fc.accum);
+	uint32_t* dbg = DBG ? fc.dbg : nullptr;
 	__shared__ unsigned long long lds_brick[8 * 256]; // 16 KiB: one 64-byte brick per thread (traverse.h brick_dma_to_lds: word k of thread t at u32 word k * 256 + t)
 	const int lane = threadIdx.x & 63;
 	const uint32_t W = static_cast<uint32_t>(fg.width), H = static_cast<uint32_t>(fg.height);
@@ -183,11 +214,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	// config 3 -1.4 %, config 5 -1.7 %, profiles/r05_event_atomics.txt)
 	float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 	auto add_rgb = [&](f3 c) {
-		if (HELP) { float* a = reinterpret_cast<float*>(accum + local_pixel); unsafeAtomicAdd(a + 0, c.x); unsafeAtomicAdd(a + 1, c.y); unsafeAtomicAdd(a + 2, c.z); }
+		if (HELP) { float* a = reinterpret_cast<float*>(accum + local_pixel); pixel_atomic_add(a + 0, c.x); pixel_atomic_add(a + 1, c.y); pixel_atomic_add(a + 2, c.z); }
 		else { acc.x += c.x; acc.y += c.y; acc.z += c.z; }
 	};
 	auto add_terminated = [&]() {
-		if (HELP) unsafeAtomicAdd(reinterpret_cast<float*>(accum + local_pixel) + 3, 1.f);
+		if (HELP) pixel_atomic_add(reinterpret_cast<float*>(accum + local_pixel) + 3, 1.f);
 		else acc.w += 1.f;
 	};
 
@@ -204,18 +235,22 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	// on another XCD's counter traces the same pixels with worse locality; tests render the same frame under both hand-outs.)
 	constexpr uint32_t kXcdTiles = 16u, kStChunks = kXcdTiles * kXcdTiles * 16u;
 	constexpr bool xcd_handout = XCD;
-	const int first_counter = xcd_handout ? static_cast<int>(blockIdx.x % kCounters)
-										  : static_cast<int>((blockIdx.x * 4u + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)))) % kCounters);
-	int my_counter = first_counter;
+	auto first_counter = [&]() {
+		return xcd_handout ? static_cast<int>(blockIdx.x % kCounters)
+						   : static_cast<int>((blockIdx.x * 4u + static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)))) % kCounters);
+	};
+	int my_counter = first_counter();
 	int counters_done = 0;
 	// hang guard only (NaN directions): no wave needs more scheduler rounds than this
-	const long long round_budget = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fg.spp) + 1) * (fg.max_bounces + 2) *
-								   (2ll * sc.cells + sc.cells_height + 64);
 	// (64-bit products are computed by the vector unit: bring the count back into scalar registers, or every test of it
 	// turns the scheduler loop's branches into exec-mask branches)
-	const long long rounds_per_frame = static_cast<long long>((static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(round_budget >> 32)))) << 32) |
-															  static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(round_budget))));
-	long long rounds_left = rounds_per_frame;
+	auto round_budget = [&]() {
+		const long long budget = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fg.spp) + 1) * (fg.max_bounces + 2) *
+								 (2ll * sc.cells + sc.cells_height + 64);
+		return static_cast<long long>((static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(budget >> 32)))) << 32) |
+									  static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(budget))));
+	};
+	long long rounds_left = round_budget();
 	uint32_t runsA = 0, lanesA = 0, runsB = 0, lanesB = 0, runsC = 0, lanesC = 0, runsD = 0, lanesD = 0, runsJ = 0, lanesJ = 0; // wave-uniform scheduler statistics
 
 	unsigned long long cycA = 0, cycB = 0, cycC = 0, cycD = 0;
@@ -233,6 +268,18 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		// ---- refill: hand pixels to idle lanes, BM_ITEM_LANES at a time (consecutive tickets walk through a 4x4 chunk)
 		const unsigned long long idle = __ballot(state == ST_IDLE);
 		const int nI = __popcll(idle);
+		if (RING && !work_left && nI == 64 && fc.frames_after > 0) {
+			// this wave has nothing left to do in its frame: on to the next frame of the launch (its constants, its buffers, its own
+			// ticket counters).  Every lane is idle here, helpers included, so nothing of the old frame is in flight in this wave;
+			// other waves may still be tracing it.
+			++ring_pos;
+			accum = reinterpret_cast<float4*>(fc.accum);
+			if (DBG) dbg = fc.dbg;
+			my_counter = first_counter();
+			counters_done = 0;
+			work_left = true;
+			rounds_left = round_budget();
+		}
 		if (work_left && nI >= fg.refill_min) {
 			// One global word serves only ~90 returning atomics per microsecond chip-wide, and a refill stalls the whole
 			// wave until its atomic returns; with thousands of waves on one counter that queue is tens of microseconds
@@ -241,7 +288,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			// the image top-down, so concurrently running waves keep working on neighbouring rows of the image.
 			const int want = nI / BM_ITEM_LANES;
 			uint32_t base = 0;
-			if (lane == 0) base = atomicAdd(work_counter + my_counter * kCounterStride, static_cast<uint32_t>(want));
+			if (lane == 0) base = atomicAdd(work_counter + (RING ? static_cast<uint32_t>(ring_pos) * static_cast<uint32_t>(kWorkCounterBytes / sizeof(uint32_t)) : 0u) + my_counter * kCounterStride, static_cast<uint32_t>(want));
 			base = __builtin_amdgcn_readfirstlane(base);
 			// units dealt to the counters: groups of four chunks, or whole super-tiles
 			const uint32_t st_x = (static_cast<uint32_t>(fg.tiles_x) + kXcdTiles - 1u) / kXcdTiles, st_y = (static_cast<uint32_t>(fg.tiles_y) + kXcdTiles - 1u) / kXcdTiles;
@@ -295,7 +342,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						s_end = sample_items ? s + 1 : fg.spp;
 						pstate = P_GEN;
 						state = ST_NEED;
-						if (!HELP) acc = atomic_acc ? make_float4(0.f, 0.f, 0.f, 0.f) : accum[local_pixel];
+						if (!HELP) acc = atomic_acc ? make_float4(0.f, 0.f, 0.f, 0.f) : pixel_load(accum + local_pixel);
 						if (DBG) {
 							d0 = 0; d1 = 0; d2 = 0xFFFFFFFFu; d3 = 0; hseg = 2166136261u; hsh = 2166136261u; next = 0; nsh = 0;
 							loads0 = tally.index_loads;
@@ -311,22 +358,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		const int nC = __popcll(__ballot(state == ST_NEED) | __ballot(state == ST_CONN)); // shade / generate, and connect (same pass)
 		const int live = nA + nB + nC;
 		--rounds_left;
-		if (rounds_left < 0 || (live == 0 && !work_left)) {
-			// this wave has nothing left to do in its frame: on to the next frame of the launch (its constants, its buffers, its
-			// own ticket counters), or out.  Every lane is idle here, helpers included, so nothing of the old frame is in flight
-			// in this wave; other waves may still be tracing it.
-			if (rounds_left < 0 || frames_left <= 0) break;
-			--frames_left;
-			++fcq;
-			accum = reinterpret_cast<float4*>(fc.accum);
-			dbg = fc.dbg;
-			work_counter += kWorkCounterBytes / sizeof(uint32_t);
-			my_counter = first_counter;
-			counters_done = 0;
-			work_left = true;
-			rounds_left = rounds_per_frame;
-			continue;
-		}
+		if (rounds_left < 0 || (live == 0 && !work_left && (!RING || fc.frames_after <= 0))) break;
+		// (live == 0 with frames left: the next round starts the next frame, see the top of the loop)
 		// (live == 0 with chunks left: only pixels outside the image were handed out; the passes below find nothing to do)
 		// Policy: an expensive phase runs once a quarter of the live lanes wait for it, the cheap connect phase
 		// once an eighth does; otherwise the DDA keeps moving.  With no lane left in the DDA the largest group runs.
@@ -371,7 +404,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						// a helper's shadow ray: the sun light goes to the OWNER's pixel (kernel.cu:341-343: atomicAdd), the lane is free again
 						if (!occluded) {
 							float* a = reinterpret_cast<float*>(accum + local_pixel);
-							unsafeAtomicAdd(a + 0, scolor.x); unsafeAtomicAdd(a + 1, scolor.y); unsafeAtomicAdd(a + 2, scolor.z);
+							pixel_atomic_add(a + 0, scolor.x); pixel_atomic_add(a + 1, scolor.y); pixel_atomic_add(a + 2, scolor.z);
 						}
 						state = ST_IDLE; // (pstate stays P_HELPER: none of the blocks below applies)
 					} else {
@@ -513,19 +546,19 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 							// (every event has been added already)
 						} else if (atomic_acc) {
 							float* a = reinterpret_cast<float*>(accum + local_pixel);
-							unsafeAtomicAdd(a + 0, acc.x); unsafeAtomicAdd(a + 1, acc.y); unsafeAtomicAdd(a + 2, acc.z); unsafeAtomicAdd(a + 3, acc.w);
+							pixel_atomic_add(a + 0, acc.x); pixel_atomic_add(a + 1, acc.y); pixel_atomic_add(a + 2, acc.z); pixel_atomic_add(a + 3, acc.w);
 						} else {
-							accum[local_pixel] = acc;
+							pixel_store(accum + local_pixel, acc);
 						}
 						if (DBG && dbg) {
-							uint32_t* d = dbg + static_cast<size_t>(local_pixel) * 8;
+							u32_in_global_memory* d = (u32_in_global_memory*)(dbg + static_cast<size_t>(local_pixel) * 8);
 							if (sample_items) {
 								// one item = one sample: the pixel's record becomes an order-independent digest -- the SUMS (mod 2^32) of
 								// the per-sample path hashes, ray counts and cell counts (the caller zeroes the buffer); the first-hit
 								// record is that of sample 0, written by the one item that traced it
 								if (s_end == 1) { d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; }
-								atomicAdd(d + 4, hseg); atomicAdd(d + 5, hsh); atomicAdd(d + 6, next | (nsh << 16));
-								atomicAdd(d + 7, tally.index_loads - loads0);
+								record_atomic_add((uint32_t*)(d + 4), hseg); record_atomic_add((uint32_t*)(d + 5), hsh); record_atomic_add((uint32_t*)(d + 6), next | (nsh << 16));
+								record_atomic_add((uint32_t*)(d + 7), tally.index_loads - loads0);
 							} else {
 								d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = hseg; d[5] = hsh; d[6] = next | (nsh << 16);
 								d[7] = tally.index_loads - loads0;
@@ -733,29 +766,37 @@ __global__ void debug_sky_kernel(const FrameConstants fc, int n, const float* __
 
 // ---- host-callable launchers (kernels.h)
 // resident 256-thread workgroups per compute unit of one instantiation (asked once per instantiation)
-template <bool DBG, bool XCD, bool HELP>
+template <bool DBG, bool XCD, bool HELP, bool RING>
 static int occupancy_of() {
 	static const int cached = [] {
 		int n = 0;
-		const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<DBG, XCD, HELP>, 256, 0);
+		const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_paths<DBG, XCD, HELP, RING>, 256, 0);
 		return e == hipSuccess && n > 0 ? n : 1;
 	}();
 	return cached;
 }
-int trace_blocks_per_cu(bool instrumented, bool xcd, bool help) {
-	if (instrumented) return xcd ? (help ? occupancy_of<true, true, true>() : occupancy_of<true, true, false>()) : (help ? occupancy_of<true, false, true>() : occupancy_of<true, false, false>());
-	return xcd ? (help ? occupancy_of<false, true, true>() : occupancy_of<false, true, false>()) : (help ? occupancy_of<false, false, true>() : occupancy_of<false, false, false>());
+// run `f` with the four instantiation choices as compile-time constants
+template <class F>
+static auto with_instantiation(bool instrumented, bool xcd, bool help, bool ring, F&& f) {
+	auto pick = [&](auto d, auto x, auto h) { return ring ? f(d, x, h, std::true_type{}) : f(d, x, h, std::false_type{}); };
+	auto pick_h = [&](auto d, auto x) { return help ? pick(d, x, std::true_type{}) : pick(d, x, std::false_type{}); };
+	auto pick_x = [&](auto d) { return xcd ? pick_h(d, std::true_type{}) : pick_h(d, std::false_type{}); };
+	return instrumented ? pick_x(std::true_type{}) : pick_x(std::false_type{});
+}
+int trace_blocks_per_cu(bool instrumented, bool xcd, bool help, bool ring) {
+	return with_instantiation(instrumented, xcd, help, ring, [](auto d, auto x, auto h, auto r) { return occupancy_of<decltype(d)::value, decltype(x)::value, decltype(h)::value, decltype(r)::value>(); });
 }
 
 // Persistent launch: exactly as many 256-thread workgroups as the device keeps resident (compute_units x
 // blocks per CU); the waves pull 4x4-pixel chunks from the ticket counters behind work_counter -- one block of kWorkCounterBytes
-// per frame of the launch, all zero at launch.  fc = the host copy of the first frame's constants (fc_dev[0]).
-void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameConstants* fc_dev, int n_frames, DeviceCounters* counters,
+// per frame of the launch (fc_dev[0], fc_dev[1], ... up to the entry with frames_after == 0), all zero at launch.  fc = the host
+// copy of the first frame's constants (fc_dev[0]).
+void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameConstants* fc_dev, DeviceCounters* counters,
 				  uint32_t* work_counter, bool instrumented, int compute_units, int blocks_per_cu_cap, hipStream_t stream) {
 	const long long chunks = static_cast<long long>(fc.tiles_x) * fc.tiles_y * 16;
 	if (chunks <= 0) return;
-	const bool xcd = fc.xcd_handout != 0;
-	int per_cu = trace_blocks_per_cu(instrumented, xcd, fc.helpers != 0); // what THIS instantiation keeps resident
+	const bool xcd = fc.xcd_handout != 0, help = fc.helpers != 0, ring = fc.frames_after > 0;
+	int per_cu = trace_blocks_per_cu(instrumented, xcd, help, ring); // what THIS instantiation keeps resident
 	if (blocks_per_cu_cap > 0 && per_cu > blocks_per_cu_cap) per_cu = blocks_per_cu_cap;
 	const long long resident_blocks = static_cast<long long>(compute_units) * per_cu;
 	long long blocks = (chunks + 15) / 16; // never more workgroups than 64-pixel groups
@@ -766,16 +807,11 @@ void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameCo
 #else
 	DeviceCounters* const plain_counters = nullptr;
 #endif
-	const bool help = fc.helpers != 0;
-#define BM_LAUNCH_TRACE(D, X, H, CNT) hipLaunchKernelGGL((trace_paths<D, X, H>), grid, block, 0, stream, sc, fc_dev, n_frames, CNT, work_counter)
-	if (instrumented) {
-		if (xcd) { if (help) BM_LAUNCH_TRACE(true, true, true, counters); else BM_LAUNCH_TRACE(true, true, false, counters); }
-		else { if (help) BM_LAUNCH_TRACE(true, false, true, counters); else BM_LAUNCH_TRACE(true, false, false, counters); }
-	} else {
-		if (xcd) { if (help) BM_LAUNCH_TRACE(false, true, true, plain_counters); else BM_LAUNCH_TRACE(false, true, false, plain_counters); }
-		else { if (help) BM_LAUNCH_TRACE(false, false, true, plain_counters); else BM_LAUNCH_TRACE(false, false, false, plain_counters); }
-	}
-#undef BM_LAUNCH_TRACE
+	DeviceCounters* const cnt = instrumented ? counters : plain_counters;
+	with_instantiation(instrumented, xcd, help, ring, [&](auto d, auto x, auto h, auto r) {
+		hipLaunchKernelGGL((trace_paths<decltype(d)::value, decltype(x)::value, decltype(h)::value, decltype(r)::value>), grid, block, 0, stream, sc, fc_dev, cnt, work_counter);
+		return 0;
+	});
 }
 
 void launch_upload(const DeviceScene& sc, const uint32_t* bricks_queue, const uint32_t* indices_queue, uint32_t* arena, uint32_t count,

@@ -350,7 +350,7 @@ class Scene:
                 assert d.is_cuda and d.dtype == torch.int32 and d.is_contiguous() and d.numel() == rows * params[i].width * 8
                 dbg_p[i] = d.data_ptr()
         if stream is None:
-            stream = torch.cuda.current_stream(accs[0].device).cuda_stream
+            stream = torch.cuda.current_stream(accs[0].device if accs else None).cuda_stream
         check(self._L.bm_render_frames(self.gpuScene, n, cam_c, par_c, acc_p, dbg_p, C.c_void_p(stream)))
 
     def resolve(self, accum, out=None, stream=None):

@@ -187,7 +187,7 @@ def test_bad_launches_are_refused(bm, orc, torch_cuda, scene256):
     with pytest.raises(bm.BrickmapError, match="1 ... 256"):
         scene256.render_frames(cam, [p] * 257, acc)
     with pytest.raises(bm.BrickmapError, match="1 ... 256"):
-        scene256.render_frames(cam, [], acc)
+        scene256.render_frames(cam, [], [])
     # what shapes the hand-out must agree
     for other in (bm.FrameParams(W, H, spp=2, max_bounces=3), bm.FrameParams(W, H, spp=1, max_bounces=2), bm.FrameParams(W, H, spp=1, max_bounces=3, flags=bm.BM_FLAG_ORDERED)):
         with pytest.raises(bm.BrickmapError, match="must agree"):
