@@ -3,38 +3,41 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one launch of the path-trace kernel over this rank's shard of the workload's frame: `spp` complete paths
-(primary + up to max_bounces bounces, one shadow ray per hit) for every pixel of the shard, scene resident in HBM.
+A "step" is one FRAME of the path-trace kernel over this rank's shard of the workload: `spp` complete paths (primary + up to
+max_bounces bounces, one shadow ray per hit) for every pixel of the shard, with its own constants (sample_base) and its own
+ticket counters, scene resident in HBM.  Consecutive steps are issued the way the reference's frame loop issues them -- one after
+the other on ONE stream (main.cpp:117-147) -- but as ONE launch of the persistent kernel per `--frames-per-launch` steps
+(bm_render_frames, the "frame ring"): a wave that finds frame i's ticket counters used up finishes its own paths
+and starts on frame i+1 by itself, so the end of a frame (the latency of the paths that started last: a sixth of a 1080p / 1-spp
+frame) is covered by the beginning of the next one instead of an idle GPU.  Nothing is skipped or shared between steps: every
+frame traces all its rays and adds them to the accumulation buffer like consecutive frames of the reference's accumulation
+(kernel.cu:319-322,341-343).  `--frames-per-launch 1` is one launch per step (what rounds 1-5 timed); the N = 1 line reports that
+figure next to the headline as `one_frame_per_launch`.
 
-N = 1 runs BASELINE.json configs[1] itself: 1920x1080, 1 spp, 4-bounce (MAX_BOUNCES = 3 -> 4 segments), 8x8x8
-superchunks, all bricks resident, one launch per step on one stream.  `--pipeline 2` issues consecutive steps on two
-alternating HIP streams, each with its own accumulation buffer, so that the next frame's workgroups take over the slots
-of the waves that have finished while the rest of the previous frame drains (more frames per second, but every
-kernel's own duration then includes the time it shares the GPU); the N = 1 line reports that mode next to the headline
-(`pipelined`), never as `value`.
+N = 1 runs BASELINE.json configs[1] itself: 1920x1080, 1 spp, 4-bounce (MAX_BOUNCES = 3 -> 4 segments), 8x8x8 superchunks, all
+bricks resident; by default all K timed steps are one launch.
 
 N > 1 STRONG-scales one fixed job with the north-star decomposition: the same 1080p / 4-segment frame at
-MULTI_GPU_SPP = 8 samples per pixel, cut into interleaved 8-row bands (band b belongs to rank b % N); every rank traces
-all 8 samples of its rows into a packed float4 buffer (work items = (4x4 chunk, sample) pairs, BM_FLAG_SAMPLE_ITEMS, so
-the persistent waves stay fed on 1/N of the pixels), and the packed bands are gathered to rank 0 over RCCL/xGMI
-(brickmap_amd/dist.py FrameGatherer: grouped send/recv, 33 MB / N per peer per step).  The gather of step i overlaps the
-tracing of step i+1; every gather, including the last, completes inside the timed region.  For N > 1 every rank issues its
-consecutive steps on two alternating streams by default (`--pipeline 2`: a 1/N shard pays the end-of-frame drain of a whole
-launch; overlapping the next step hides it -- DESIGN.md 6); the exchange itself is the C-ABI's bm_gather_frame (csrc/comm.hip).  Rates are per nominal ray,
-but the N = 1 line is a DIFFERENT work shape (1 spp, pixel items; its end-of-frame drain is not amortised over samples,
-and coherent neighbouring samples run ~20 % faster per ray), so a scaling efficiency must not be computed against it:
-every N > 1 line carries `same_job_single_gpu` (rank 0 renders the line's own 8-spp job unsharded, untimed) and the
-N = 1 line carries the same figure as `multi_gpu_job_on_one_gpu` -- that is the denominator.
-`--decomposition samples` keeps the alternative cut (every rank the full frame with its own samples, ONE sum-reduction
-after the last step -- the buffers are additive), `--scaling weak` makes the job grow with N (N spp in total).
+MULTI_GPU_SPP = 8 samples per pixel, cut into interleaved 8-row bands (band b belongs to rank b % N); every rank traces all 8
+samples of its rows into a packed float4 buffer (work items = (4x4 chunk, sample) pairs, BM_FLAG_SAMPLE_ITEMS, so the persistent
+waves stay fed on 1/N of the pixels), five steps per launch by default, each into its own packed buffer of one allocation, and the
+batch is gathered to rank 0 over RCCL/xGMI as ONE message per peer (brickmap_amd/dist.py FrameGatherer -> bm_gather_frames:
+grouped send/recv, 33 MB / N per peer per step).  The gather of batch i overlaps the tracing of batch i+1 (one render stream, the
+exchange on a side stream); every gather, including the last, completes inside the timed region.  Rates are per nominal ray, but
+the N = 1 line is a DIFFERENT work shape (1 spp, pixel items; coherent neighbouring samples run ~20 % faster per ray), so a
+scaling efficiency must not be computed against it: every N > 1 line carries `same_job_single_gpu` (rank 0 renders the line's own
+8-spp job unsharded, untimed) and the N = 1 line carries the same figure as `multi_gpu_job_on_one_gpu` -- that is the denominator.
+`--decomposition samples` keeps the alternative cut (every rank the full frame with its own samples, ONE sum-reduction after the
+last step -- the buffers are additive), `--scaling weak` makes the job grow with N (N spp in total).
 
 metric: Mrays/s = width * height * spp_total * segments / seconds  (nominal rays).
-The line also carries `roofline` (algorithmic bytes of the kernel / its HIP-event duration against the 8 TB/s HBM
+The line also carries `roofline` (algorithmic bytes of the timed launches / their HIP-event duration against the 8 TB/s HBM
 peak) and, on rank 0 at N = 1, `cpu_baseline` (the oracle's scalar C port of the same path timed on the host cores).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -43,15 +46,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# what bounds trace_paths on each workload (profiles/r0x_pmc_summary_<workload>.json, profiles/r03_fetch_calibration.txt)
+# what bounds trace_paths on each workload (profiles/r0x_pmc_summary_<workload>.json, profiles/r03_fetch_calibration.txt); {waves} = resident
+# waves per SIMD of the instantiation that ran, asked from the library (bm_trace_waves_per_simd)
 LIMITER = {
-    "config2": "VALU issue at the occupancy the registers allow (6 waves per SIMD): the vector pipes are busy for most of the launch with ~21 of 64 lanes active per "
+    "config2": "VALU issue at the occupancy the registers allow ({waves} waves per SIMD): the vector pipes are busy for most of the launch with ~21 of 64 lanes active per "
                "instruction (a wave's lanes are in different states; a pass costs the same with 15 or 64 of them); the scene (110 MiB) stays in L2 / Infinity Cache",
-    "config3": "VALU issue (7 waves per SIMD, ~23 of 64 lanes), with 0.4 G single-sector reads reaching the fabric per launch (XCD-aware hand-out)",
+    "config3": "VALU issue ({waves} waves per SIMD, ~23 of 64 lanes), with 0.4 G single-sector reads reaching the fabric per launch (XCD-aware hand-out)",
     "config5": "VALU issue (79 G wave instructions at ~20 of 64 lanes) together with the fabric's request rate for single 64-byte sectors (every read of the walk is one "
-               "sector; the GPU sustains ~48 G such requests/s); occupancy (7 waves per SIMD) is what hides the walk's dependent loads",
+               "sector; the GPU sustains ~48 G such requests/s); occupancy ({waves} waves per SIMD) is what hides the walk's dependent loads",
 }
-PROFILE_ROUNDS = ("r05", "r04", "r03")  # profiles/<round>_pmc_summary_<workload>.json is where roofline.traffic comes from (newest first)
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03")  # profiles/<round>_pmc_summary_<workload>.json is where roofline.traffic comes from (newest first)
+TUNING_VARIABLES = ("BM_REFILL_MIN", "BM_XCD_HANDOUT", "BM_HELPERS", "BM_TRACE_BLOCKS_PER_CU")  # what bm_tuning_overrides reports: the library's A/B knobs
+MULTI_FRAMES_PER_LAUNCH = 5  # N > 1: steps per launch and per exchange (the last batch's gather is not hidden by a next batch: keep it short)
 
 
 def workload(name):
@@ -69,6 +75,20 @@ def workload(name):
     return table[name]
 
 
+def batches(first, count, per_launch):
+    """[(first step, steps)] of `count` consecutive steps cut into launches of at most `per_launch` (as even as possible)."""
+    if count <= 0:
+        return []
+    n = -(-count // max(1, per_launch))
+    base, extra = divmod(count, n)
+    out, at = [], first
+    for i in range(n):
+        size = base + (1 if i < extra else 0)
+        out.append((at, size))
+        at += size
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,16 +101,15 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="N > 1: strong = the fixed job (frame at --multi-gpu-spp samples) over N ranks; weak = N x spp samples in total")
     ap.add_argument("--multi-gpu-spp", type=int, default=8, help="samples per pixel of the strong-scaled job (N > 1)")
-    ap.add_argument("--pipeline", type=int, default=None,
-                    help="resident scenes: consecutive steps are issued on this many alternating HIP streams (one accumulation buffer each), "
-                         "so that the next frame's workgroups start while the previous frame drains; 1 = one stream.  Default: 1 for "
-                         "--gpus 1 (the headline is one kernel at a time, so that its own duration is what the roofline prices), 2 for "
-                         "--gpus N > 1 (every rank overlaps its consecutive shard steps: a 1/N shard pays the end-of-frame drain of a "
-                         "whole launch, DESIGN.md 6)")
+    ap.add_argument("--frames-per-launch", type=int, default=0,
+                    help="consecutive steps issued as ONE launch of the persistent kernel (bm_render_frames, the frame ring): every step keeps its own "
+                         "constants, ticket counters and rays; waves walk from a used-up frame to the next by themselves.  0 = default: all timed steps "
+                         "(at most 256 per launch) for --gpus 1, %d per launch and per exchange for --gpus N > 1, 1 for streaming workloads (bricks are "
+                         "serviced between launches).  1 = one launch per step, what rounds 1-5 timed" % MULTI_FRAMES_PER_LAUNCH)
     ap.add_argument("--verify", action="store_true",
                     help="N > 1: after the timed region rank 0 renders every step unsharded and compares it with the gathered / reduced frame")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the untimed extra measurements of the N = 1 line (two-stream figures, the 4-spp north-star shape): "
+                    help="skip the untimed extra measurements of the N = 1 line (one launch per frame, the 4-spp north-star shape, the shard predictions): "
                          "used when the run is profiled, so that rocprofv3's per-kernel averages cover the timed launches")
     ap.add_argument("--streaming-mode", choices=["overlapped", "blocking"], default="overlapped",
                     help="streaming workloads: overlapped = two request rings, the host never waits for the GPU; blocking = the reference's order")
@@ -101,14 +120,18 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` with no launcher: start the N ranks ourselves (one process per GPU; rank 0 prints the line)
         raise SystemExit(self_launch(args.gpus))
-    if args.pipeline is None:
-        args.pipeline = 1 if (args.gpus == 1 and os.environ.get("BM_BENCH_FORCE_DIST") != "1") else 2
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
     import brickmap_amd as bm
+
+    # the library's tuning knobs are read from the environment: a stray variable on a lease would silently change what is timed.
+    # Echoed into the line (config.env_overrides); BM_BENCH_STRICT=1 refuses to produce a number under any of them.
+    overrides = bm.tuning_overrides()
+    if overrides and os.environ.get("BM_BENCH_STRICT") == "1":
+        raise SystemExit(f"bench.py: BM_BENCH_STRICT=1 and tuning overrides are set: {overrides}")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -173,13 +196,16 @@ def main():
             raise SystemExit("--schedule wavefront does not shard (replicas only): run it with --gpus 1")
         return bench_wavefront(args, bm, torch, np, scene, cam, accum, W, H, max_bounces, n_super, G, streaming, build_s)
 
-    # Everything resident: pipeline consecutive frames over `pipeline` streams.  A fifth of a 1080p-sample frame is the drain
-    # (waves working their last paths off, docs/HISTORY.md 5.2); the next frame's workgroups fill the freed slots.  Every stream
-    # has its OWN accumulation buffer (frame i adds into buffer i % pipeline), so no two frames in flight touch the same
-    # pixel record and the default, deterministic accumulation can be used; the image is the sum of the buffers.
-    pipeline = max(1, args.pipeline) if not streaming else 1
-    streams = None  # chosen below (HIP maps streams onto a few hardware queues: not every pair overlaps)
-    accums = [accum] + [torch.zeros_like(accum) for _ in range(pipeline - 1)]
+    # ---- how the steps are issued: the frame ring (module docstring).  Streaming workloads service their brick requests between
+    # launches (bm_scene_process_load_queue): one step per launch there.
+    if streaming:
+        per_launch = 1
+    elif args.frames_per_launch > 0:
+        per_launch = min(args.frames_per_launch, 256)
+    elif by_rows:
+        per_launch = min(MULTI_FRAMES_PER_LAUNCH, max(args.steps, 1))
+    else:
+        per_launch = min(max(args.steps, 1), 256)
     item_flag = bm.BM_FLAG_SAMPLE_ITEMS if multi else 0  # (chunk, sample) work items keep 1/N-of-the-pixels shards fed
 
     def params(step, flags=0):
@@ -189,39 +215,12 @@ def main():
         # sample shards: rank r owns samples [step*spp_total + r*spp_rank, ... + spp_rank) of every pixel
         return bm.FrameParams(W, H, spp=spp_rank, sample_base=step * spp_total + rank * spp_rank, max_bounces=max_bounces, flags=flags | item_flag)
 
-    # rows: the gather of frame i runs on RCCL's stream while frame i+1 is being traced (one gather in flight);
-    # samples: ONE sum-reduction after the last step (the per-rank buffers are additive)
-    gatherer = None  # made below, once the streams are chosen
+    # rows: every step of a launch goes into its own packed buffer of ONE allocation (slot = position in the launch), and the batch is
+    # gathered as one message per peer while the next batch is traced (one gather in flight); the buffers keep accumulating from
+    # batch to batch.  samples: ONE sum-reduction after the last step (the per-rank buffers are additive).
+    batch_buf = torch.zeros((per_launch,) + tuple(accum.shape), dtype=torch.float32, device=dev) if by_rows else None
+    gatherer = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev, force_collective=True, frames=per_launch) if by_rows else None
     reducer = bm.dist.FrameReducer(H, W, device=dev, force_collective=True) if (multi and not by_rows) else None
-
-    def pick_streams(count):
-        """Which streams run concurrently is a property of how the runtime maps them onto hardware queues; pick the group of
-        `count` streams (out of a few more) on which a short burst of work finishes first (probed with torch's spin
-        kernel, one thread busy for ~0.2 ms: no frame is rendered for this)."""
-        import itertools
-        pool = [torch.cuda.Stream() for _ in range(count + 3)]
-        best = None
-        for combo in itertools.combinations(range(len(pool)), count):
-            tc = 0.0
-            for rep in range(3):
-                torch.cuda.synchronize()
-                t_c = time.perf_counter()
-                for i in combo:
-                    with torch.cuda.stream(pool[i]):
-                        torch.cuda._sleep(400_000)
-                torch.cuda.synchronize()
-                tc = (time.perf_counter() - t_c) if rep == 0 else min(tc, time.perf_counter() - t_c)
-            if best is None or tc < best[0] * 0.9:
-                best = (tc, combo)
-        return [pool[i] for i in best[1]]
-
-    gather_side = None
-    if pipeline > 1:
-        # (one stream more for the exchange: it must not share a hardware queue with a render stream, see FrameGatherer)
-        picked = pick_streams(pipeline + (1 if by_rows else 0))
-        streams, gather_side = picked[:pipeline], (picked[pipeline] if by_rows else None)
-    if by_rows:
-        gatherer = bm.dist.FrameGatherer(H, W, band_rows=band, device=dev, force_collective=True, side_stream=gather_side)
 
     exchange_error = None
     if multi and not share_gpu and os.environ.get("BM_DIST_TORCH", "0") != "1":
@@ -237,32 +236,27 @@ def main():
             if os.environ.get("BM_BENCH_STRICT") == "1":
                 raise SystemExit("bench.py " + exchange_error)
 
-    gathered = {}  # --verify: the last gathered frame of every accumulation buffer (rank 0)
+    gathered = {}  # --verify: the last gathered batch (rank 0): slot k holds everything step-slot k accumulated
 
-    def keep(step, frame):
-        if args.verify and frame is not None and step >= 0:
-            gathered[step % pipeline] = frame.clone()
+    def keep(batch):
+        if args.verify and batch is not None:
+            gathered["batch"] = batch.clone()
 
-    def one_step(step):
-        j = step % pipeline
-        if streams is not None:
-            scene.render(cam, params(step), accums[j], stream=streams[j].cuda_stream)
-            if gatherer is not None:
-                # frame step-1 is complete on rank 0 once its gather is (frame `step` is already running on the other stream); only
-                # --verify looks at it here.  start() orders the snapshot behind the previous gather on the frame's own stream.
-                keep(step - 1, gatherer.finish(wait=args.verify))
-                if args.verify:
-                    streams[j].wait_stream(torch.cuda.current_stream())  # (the copy keep() just queued reads the frame the next gather overwrites)
-                with torch.cuda.stream(streams[j]):
-                    gatherer.start(accums[j])  # snapshot behind frame `step` on its stream + asynchronous gather of its packed bands
-            return accums[j]
-        scene.render(cam, params(step), accum)
-        if streaming:
-            scene.process_load_queue()
-        if gatherer is not None:
-            keep(step - 1, gatherer.finish())  # frame step-1 is complete on rank 0
-            gatherer.start(accum)              # snapshot + asynchronous gather of this frame's packed bands
-        return accum
+    def issue(first, count):
+        """`count` consecutive steps starting at step `first`: one launch (streaming: one launch + request servicing)"""
+        ps = [params(first + i) for i in range(count)]
+        if by_rows:
+            scene.render_frames(cam, ps, [batch_buf[k] for k in range(count)])
+            if streaming:
+                scene.process_load_queue()
+            keep(gatherer.finish(wait=args.verify))  # the previous batch is complete on rank 0 (only --verify looks at it here)
+            gatherer.start(batch_buf)                # snapshot + asynchronous gather of this batch's packed bands
+        elif count == 1:
+            scene.render(cam, ps[0], accum)
+            if streaming:
+                scene.process_load_queue()
+        else:
+            scene.render_frames(cam, ps, accum)
 
     if streaming:  # reach streaming steady state before anything is timed
         for i in range(64):
@@ -271,24 +265,21 @@ def main():
                 break
         accum.zero_()
 
-    for i in range(args.warmup):
-        one_step(i)
+    for first, count in batches(0, args.warmup, per_launch):
+        issue(first, count)
     if gatherer is not None:
-        keep(args.warmup - 1, gatherer.finish())
+        keep(gatherer.finish())
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
+    timed = batches(args.warmup, args.steps, per_launch)
     t_start = time.perf_counter()
-    for i in range(args.steps):
-        one_step(args.warmup + i)
+    for first, count in timed:
+        issue(first, count)
     if gatherer is not None:
-        keep(args.warmup + args.steps - 1, gatherer.finish())  # the last frame's gather is inside the timed region
+        keep(gatherer.finish())  # the last batch's gather is inside the timed region
     if reducer is not None:
-        if streams is not None:
-            torch.cuda.synchronize()
-            for extra in accums[1:]:
-                accum.add_(extra)  # the image is the sum of the per-stream buffers
         reducer.start(accum)
         reduced = reducer.finish()
     torch.cuda.synchronize()
@@ -296,7 +287,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
-    kernel_ms = scene.render_times(args.steps)  # HIP events on the launch stream, one pair per launch
+    launch_ms = scene.render_times(len(timed))  # HIP events on the launch stream, one pair per launch
+    kernel_ms_per_step = float(np.sum(launch_ms)) / args.steps
     ranks_info = None
     if multi:
         # every rank's own clock and device, for the line: an imbalance (or two ranks on one GPU) shows up in SCALE_rNN.json
@@ -304,13 +296,13 @@ def main():
         comm_world = ex.comm.info()[1] if getattr(ex, "comm", None) is not None else None
         mine = {"rank": rank, "device": torch.cuda.get_device_name(local_rank), "device_index": local_rank,
                 "pci_bus_id": getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None),
-                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "kernel_ms_avg": round(float(np.mean(kernel_ms)), 4)}
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4), "kernel_ms_per_step": round(kernel_ms_per_step, 4)}
         every = [None] * world
         dist.all_gather_object(every, mine)
         ranks_info = {"process_group_world": dist.get_world_size(), "process_group_backend": dist.get_backend(),
                       "exchange_error": exchange_error,  # None: the C-ABI exchange passed its self-test on this rank (a failure on any rank makes all fall back)
                       "communicator_world": comm_world,  # bm_comm_info of the C-ABI communicator the frames travelled through (None: torch.distributed's exchange)
-                      "ms_per_step": [e["ms_per_step"] for e in every], "kernel_ms_avg": [e["kernel_ms_avg"] for e in every],
+                      "ms_per_step": [e["ms_per_step"] for e in every], "kernel_ms_per_step": [e["kernel_ms_per_step"] for e in every],
                       "devices": [f'{e["device"]} #{e["device_index"]}' + (f' {e["pci_bus_id"]}' if e["pci_bus_id"] is not None else "") for e in every]}
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -320,151 +312,145 @@ def main():
     verified = None
     if args.verify and multi and rank == 0:
         want = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+        if streaming and by_rows:  # this rank has streamed in what ITS rows see: reach the whole frame's steady state before rendering it
+            for i in range(64):
+                scene.render(cam, bm.FrameParams(W, H, spp=1, max_bounces=max_bounces), want)
+                if scene.process_load_queue() == 0 and i > 2:
+                    break
+            want.zero_()
         for i in range(args.warmup + args.steps):
             scene.render(cam, bm.FrameParams(W, H, spp=spp_total, sample_base=i * spp_total, max_bounces=max_bounces), want)
         torch.cuda.synchronize()
-        have = sum(gathered.values()) if by_rows else reduced
+        have = gathered["batch"].sum(dim=0) if by_rows else reduced  # (the batch's slots together hold every step)
         err = float((have.to(dev) - want).abs().max() / want.abs().max())
         if not err < 1e-5:  # bit-identical paths; only the order of the float additions differs
             raise SystemExit(f"--verify: the {world}-rank frame differs from the single-GPU frame (relative error {err:g})")
         verified = {"frames": args.warmup + args.steps, "max_rel_err": err}
 
-    # ---- the same steps pipelined over two streams (one accumulation buffer each), for the record: N = 1 / resident only
-    pipelined = None
-    if pipeline == 1 and not multi and not streaming and not args.no_extras:
-        try:  # an extra: whatever goes wrong here must not cost the headline measurement above
-            two = pick_streams(2)
-            bufs = [accum, torch.zeros_like(accum)]
-            for rep in range(2):  # the first repetition warms the second stream up
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for i in range(args.steps):
-                    scene.render(cam, params(args.warmup + i), bufs[i % 2], stream=two[i % 2].cuda_stream)
-                torch.cuda.synchronize()
-                e1 = time.perf_counter() - t1
-            pipelined = {"streams": 2, "ms_per_step": round(e1 / args.steps * 1e3, 4), "value": round(W * H * spp_total * segments * args.steps / e1 / 1e6, 3),
-                         "kernel_ms_avg": round(float(np.mean(scene.render_times(args.steps))), 4),
-                         "note": "consecutive steps on two alternating streams, one accumulation buffer per stream: the next frame's workgroups start "
-                                 "while the previous frame drains; a kernel's own duration then includes the time it shares the GPU"}
-        except Exception as e:  # noqa: BLE001
-            torch.cuda.synchronize()
-            pipelined = {"error": repr(e)}
-
-    # ---- algorithmic bytes of exactly the timed launches, from the instrumented kernel variant (not timed)
+    # ---- algorithmic bytes of exactly the timed steps, from the instrumented kernel variant (not timed; same launches, same scheduling)
     scene.counters_reset()
     scratch = torch.zeros_like(accum)
-    for i in range(args.steps):
-        scene.render(cam, params(args.warmup + i, flags=bm.BM_FLAG_COUNTERS), scratch)
+    for first, count in timed:
+        ps = [params(first + i, flags=bm.BM_FLAG_COUNTERS) for i in range(count)]
+        if count == 1:
+            scene.render(cam, ps[0], scratch)
+        else:
+            scene.render_frames(cam, ps, scratch)
     cnt = scene.counters()
     local_rows = state.local_rows
     alg_bytes = 4 * cnt["index_loads"] + 64 * cnt["brick_tests"] + 16 * W * local_rows * args.steps
-    avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3
-    achieved_gbs = alg_bytes / args.steps / avg_kernel_s / 1e9
+    kernel_s = float(np.sum(launch_ms)) * 1e-3  # all timed launches
+    achieved_gbs = alg_bytes / kernel_s / 1e9
     actual_rays = cnt["extend_rays"] + cnt["shadow_rays"]
+    bytes_per_step = alg_bytes / args.steps
 
     nominal_rays_per_step = W * H * spp_total * segments
     value = nominal_rays_per_step * args.steps / elapsed / 1e6
+    extras = not args.no_extras
+
+    def measure(render_one, frames, reps=2):
+        """wall seconds per frame of `frames` frames issued by render_one(i), best of `reps` (after one untimed pass)"""
+        best = None
+        for rep in range(reps + 1):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(frames):
+                render_one(rep * frames + i)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t1) / frames
+            if rep > 0:
+                best = dt if best is None else min(best, dt)
+        return best
+
+    # ---- one launch per frame on the same stream (what rounds 1-5 reported as the headline), for the record: N = 1 / resident only
+    single = None
+    if not multi and not streaming and extras and per_launch > 1:
+        try:  # an extra: whatever goes wrong here must not cost the headline measurement above
+            s1 = measure(lambda i: scene.render(cam, params(args.warmup + i), scratch), args.steps)
+            k1 = float(np.mean(scene.render_times(args.steps))) * 1e-3
+            single = {"ms_per_step": round(s1 * 1e3, 4), "value": round(nominal_rays_per_step / s1 / 1e6, 3), "kernel_ms_avg": round(k1 * 1e3, 4),
+                      "roofline_frac": round(bytes_per_step / k1 / 1e9 / HBM_PEAK_GBS, 5),
+                      "note": "the same steps as one launch each (bm_render_frame) on the same stream: the end of every frame -- the latency of its last paths -- "
+                              "is an idle GPU; rounds 1-5 reported this as `value`"}
+        except Exception as e:  # noqa: BLE001
+            torch.cuda.synchronize()
+            single = {"error": repr(e)}
 
     # ---- the north-star target shape (BASELINE.json: "1080p, 4 spp, 4-bounce"), N = 1 / config 2 only, reported next to the
-    # headline, never as `value`: the same frame at 4 samples per pixel with (chunk, sample) work items
+    # headline, never as `value`: the same frame at 4 samples per pixel with (chunk, sample) work items -- one launch per frame, and
+    # five consecutive frames as one launch
     target4 = None
-    if not multi and args.workload == "config2" and not streaming and not args.no_extras:
+    if not multi and args.workload == "config2" and not streaming and extras:
         n4 = 5
         p4 = lambda i, flags=0: bm.FrameParams(W, H, spp=4, sample_base=1000 + 4 * i, max_bounces=max_bounces, flags=flags | bm.BM_FLAG_SAMPLE_ITEMS)
-        for i in range(2):
-            scene.render(cam, p4(i), scratch)
-        torch.cuda.synchronize()
-        t4 = time.perf_counter()
-        for i in range(n4):
-            scene.render(cam, p4(2 + i), scratch)
-        torch.cuda.synchronize()
-        s4 = (time.perf_counter() - t4) / n4
+        s4 = measure(lambda i: scene.render(cam, p4(i), scratch), n4)
         k4 = float(np.mean(scene.render_times(n4))) * 1e-3
         scene.counters_reset()
         scene.render(cam, p4(2, flags=bm.BM_FLAG_COUNTERS), scratch)
         c4 = scene.counters()
         b4 = 4 * c4["index_loads"] + 64 * c4["brick_tests"] + 16 * W * H
+        r4 = measure(lambda i: scene.render_frames(cam, [p4(n4 * i + k) for k in range(n4)], scratch), 1) / n4
         target4 = {"workload": f"{W}x{H}, 4 spp, {segments} segments/path, (chunk, sample) work items", "ms_per_step": round(s4 * 1e3, 4),
                    "Mrays_s": round(W * H * 4 * segments / s4 / 1e6, 1), "kernel_ms_avg": round(k4 * 1e3, 4),
-                   "roofline_frac": round(b4 / k4 / 1e9 / HBM_PEAK_GBS, 5)}
+                   "roofline_frac": round(b4 / k4 / 1e9 / HBM_PEAK_GBS, 5),
+                   "frame_ring": {"frames_per_launch": n4, "ms_per_step": round(r4 * 1e3, 4), "Mrays_s": round(W * H * 4 * segments / r4 / 1e6, 1),
+                                  "roofline_frac": round(b4 / r4 / 1e9 / HBM_PEAK_GBS, 5)}}
 
     # ---- the denominator of a scaling efficiency: the N > 1 lines strong-scale ONE fixed job (the frame at spp_total samples,
     # (chunk, sample) work items); rank 0 renders exactly that job unsharded on its GPU, untimed, so that value(N) can be
-    # compared with the single-GPU time of ITS OWN job and not with the N = 1 line's 1-spp frame (whose end-of-frame drain
-    # is not amortised over samples).  The N = 1 line carries the same measurement for the default 8-spp job.
+    # compared with the single-GPU time of ITS OWN job and not with the N = 1 line's 1-spp frame.  Measured the way the N > 1 ranks
+    # issue their steps (MULTI_FRAMES_PER_LAUNCH steps per launch) and as one launch per step.  The N = 1 line carries the same
+    # measurement for its workload's multi-GPU job (config 2: the default 8-spp job).
     same_job = None
     job_spp = spp_total if multi else (max(args.multi_gpu_spp, 1) if args.workload == "config2" else spp * 8)
-    if rank == 0 and not streaming and not args.no_extras:
+    nj = MULTI_FRAMES_PER_LAUNCH
+    if rank == 0 and not streaming and extras:
         try:
             whole = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
             pj = lambda i: bm.FrameParams(W, H, spp=job_spp, sample_base=5000 + i * job_spp, max_bounces=max_bounces, flags=bm.BM_FLAG_SAMPLE_ITEMS)
-            nj = 3
-            scene.render(cam, pj(0), whole)
-            torch.cuda.synchronize()
-            tj = time.perf_counter()
-            for i in range(nj):
-                scene.render(cam, pj(1 + i), whole)
-            torch.cuda.synchronize()
-            sj = (time.perf_counter() - tj) / nj
+            reps = 2 if W * H * job_spp < 100e6 else 1
+            s_one = measure(lambda i: scene.render(cam, pj(i), whole), 3, reps=reps)
+            k_one = float(np.mean(scene.render_times(3)))
+            s_ring = measure(lambda i: scene.render_frames(cam, [pj(nj * i + k) for k in range(nj)], whole), 1, reps=reps) / nj
             same_job = {"workload": f"{W}x{H}, {job_spp} spp, {segments} segments/path, (chunk, sample) work items, unsharded on one GPU",
-                        "ms_per_step": round(sj * 1e3, 4), "Mrays_s": round(W * H * job_spp * segments / sj / 1e6, 1),
-                        "kernel_ms_avg": round(float(np.mean(scene.render_times(nj))), 4)}
+                        "ms_per_step": round(s_ring * 1e3, 4), "Mrays_s": round(W * H * job_spp * segments / s_ring / 1e6, 1), "frames_per_launch": nj,
+                        "one_frame_per_launch": {"ms_per_step": round(s_one * 1e3, 4), "kernel_ms_avg": round(k_one, 4)}}
             del whole
         except Exception as e:  # noqa: BLE001 -- an extra: must not cost the headline measurement
             torch.cuda.synchronize()
             same_job = {"error": repr(e)}
 
-    # ---- what the N > 1 lines should come out at, measured on THIS GPU (N = 1 / config 2 line only, untimed extra): every rank's
-    # 1/N shard of the same 8-spp job (interleaved row bands, (chunk, sample) items; the slowest rank counts), N = 2 / 4 / 8, consecutive steps on one
-    # stream.  predicted_speedup = unsharded job time / shard time: the kernels alone, before the gather (4.1 MB per peer per
-    # step at N = 8, issued behind the frame and overlapped with the next one).  The first real SCALE run is checked against it.
+    # ---- what the N > 1 lines should come out at, measured on THIS GPU (N = 1 line only, untimed extra): every rank's 1/N shard of
+    # the job (interleaved row bands, (chunk, sample) items; the slowest rank counts), consecutive steps on ONE stream, issued as the
+    # ranks issue them (MULTI_FRAMES_PER_LAUNCH steps per launch).  predicted_speedup = unsharded job time / shard time, both issued
+    # the same way: the kernels alone, before the exchange (4.1 MB per peer per step at N = 8 for the 1080p job, one message per
+    # batch, overlapped with the next batch).  The first real SCALE run is checked against it.  config 2: N = 2 / 4 / 8; the big
+    # workloads: N = 8 (what BASELINE.json configs 4 / 5 name).
     shard_pred = None
-    if not multi and args.workload == "config2" and not streaming and not args.no_extras and same_job is not None and "ms_per_step" in same_job:
+    if not multi and not streaming and extras and same_job is not None and "ms_per_step" in same_job:
         try:
-            shard_pred = {"job": same_job["workload"], "unsharded_ms_per_step": same_job["ms_per_step"], "shard_kernel_ms": {}, "shard_ms_per_step": {},
-                          "predicted_speedup": {}, "note": "every rank's shard of the job timed on this GPU, one after the other, no gather; shard_* = the SLOWEST rank.  --gpus N runs every rank's steps on two alternating streams by default: "
-                          "value(N) / (the unsharded job's rate on one GPU) should come out near predicted_speedup_two_streams[N] "
-                          "(predicted_speedup[N] with --pipeline 1)"}
-            two = pick_streams(2)
-            shard_pred["shard_ms_per_step_two_streams"], shard_pred["predicted_speedup_two_streams"] = {}, {}
-            shard_pred["band_rows"] = band
-            shard_pred["per_rank_ms_per_step"], shard_pred["per_rank_ms_per_step_two_streams"] = {}, {}
-            for n_ranks in (2, 4, 8):
-                # EVERY rank's shard, one after the other: the job is as fast as its slowest rank (the bands differ in rows -- 1080 rows
-                # are 135 bands of 8 -- and in what they show)
-                ones, twos, kern = [], [], []
+            shard_pred = {"job": same_job["workload"], "frames_per_launch": nj, "unsharded_ms_per_step": same_job["ms_per_step"],
+                          "unsharded_ms_per_step_one_frame_per_launch": same_job["one_frame_per_launch"]["ms_per_step"],
+                          "shard_ms_per_step": {}, "predicted_speedup": {}, "shard_ms_per_step_one_frame_per_launch": {}, "predicted_speedup_one_frame_per_launch": {},
+                          "per_rank_ms_per_step": {}, "band_rows": band,
+                          "note": "every rank's shard of the job timed on this GPU, one after the other, on ONE stream, no exchange; shard_* = the SLOWEST rank.  "
+                                  "value(N) / (the unsharded job's rate on one GPU) of a --gpus N run should come out near predicted_speedup[N]"}
+            for n_ranks in ((2, 4, 8) if args.workload == "config2" else (8,)):
+                ring_ms, one_ms = [], []
                 for r in range(n_ranks):
                     st = bm.State(W, H, device=local_rank, band_rows=band, shard_rank=r, shard_count=n_ranks)
-                    bufs = [st.blit_buffer, torch.zeros_like(st.blit_buffer)]
                     ps = lambda i: bm.FrameParams(W, H, spp=job_spp, sample_base=7000 + i * job_spp, max_bounces=max_bounces, flags=bm.BM_FLAG_SAMPLE_ITEMS,
                                                   band_rows=band, shard_rank=r, shard_count=n_ranks)
-                    ns = 6
-                    for i in range(2):
-                        scene.render(cam, ps(i), st.blit_buffer)
-                    torch.cuda.synchronize()
-                    ts = time.perf_counter()
-                    for i in range(ns):
-                        scene.render(cam, ps(2 + i), st.blit_buffer)
-                    torch.cuda.synchronize()
-                    ones.append((time.perf_counter() - ts) / ns * 1e3)
-                    kern.append(float(np.mean(scene.render_times(ns))))
-                    for rep in range(2):  # (the first repetition warms the second stream up)
-                        torch.cuda.synchronize()
-                        ts = time.perf_counter()
-                        for i in range(2 * ns):
-                            scene.render(cam, ps(10 + i), bufs[i % 2], stream=two[i % 2].cuda_stream)
-                        torch.cuda.synchronize()
-                        s2 = (time.perf_counter() - ts) / (2 * ns) * 1e3
-                    twos.append(s2)
-                    del st, bufs
+                    reps = 2 if W * H * job_spp < 100e6 else 1
+                    ring_ms.append(measure(lambda i: scene.render_frames(cam, [ps(nj * i + k) for k in range(nj)], st.blit_buffer), 1, reps=reps) / nj * 1e3)
+                    one_ms.append(measure(lambda i: scene.render(cam, ps(i), st.blit_buffer), 4, reps=reps) * 1e3)
+                    del st
                 key = str(n_ranks)
-                shard_pred["per_rank_ms_per_step"][key] = [round(t, 4) for t in ones]
-                shard_pred["per_rank_ms_per_step_two_streams"][key] = [round(t, 4) for t in twos]
-                shard_pred["shard_ms_per_step"][key] = round(max(ones), 4)
-                shard_pred["shard_kernel_ms"][key] = round(max(kern), 4)
-                shard_pred["predicted_speedup"][key] = round(same_job["ms_per_step"] / max(ones), 3)
-                shard_pred["shard_ms_per_step_two_streams"][key] = round(max(twos), 4)
-                shard_pred["predicted_speedup_two_streams"][key] = round(same_job["ms_per_step"] / max(twos), 3)
+                shard_pred["per_rank_ms_per_step"][key] = [round(t, 4) for t in ring_ms]
+                shard_pred["shard_ms_per_step"][key] = round(max(ring_ms), 4)
+                shard_pred["predicted_speedup"][key] = round(same_job["ms_per_step"] / max(ring_ms), 3)
+                shard_pred["shard_ms_per_step_one_frame_per_launch"][key] = round(max(one_ms), 4)
+                shard_pred["predicted_speedup_one_frame_per_launch"][key] = round(same_job["one_frame_per_launch"]["ms_per_step"] / max(one_ms), 3)
         except Exception as e:  # noqa: BLE001 -- an extra: must not cost the headline measurement
             torch.cuda.synchronize()
             shard_pred = {"error": repr(e)}
@@ -476,6 +462,11 @@ def main():
             dist.destroy_process_group()
         return
 
+    # the instantiation that ran and what it keeps resident, from the library's own plan of the timed frames
+    plan = bm.frame_plan(params(args.warmup))
+    ring = per_launch > 1 and any(c > 1 for _, c in timed)
+    waves = bm.trace_waves_per_simd(instrumented=False, xcd_handout=bool(plan["xcd_handout"]), helpers=bool(plan["helpers"]), device=local_rank)
+    kernel_name = "bm::trace_paths<false, %s, %s, %s>" % tuple("true" if b else "false" for b in (plan["xcd_handout"], plan["helpers"], ring))
     out = {
         "metric": "Mrays/sec (primary x spp x bounces) at 1080p 4-bounce",
         "value": round(value, 3),
@@ -496,54 +487,52 @@ def main():
                         + ("" if world == 1 else f"; the fixed {spp_total}-spp job strong-scaled over {world} ranks" if args.scaling == "strong"
                            else f"; weak scaling, {spp_total // world} spp per rank"),
             "width": W, "height": H, "spp_per_step": spp_total, "segments": segments, "world_voxels": G,
+            "step_issue": ("one launch per step (bm_render_frame) + bm_scene_process_load_queue" if per_launch == 1 else
+                           f"frame ring: {[c for _, c in timed]} consecutive steps per launch of the persistent kernel (bm_render_frames) on one stream; every step is a "
+                           "complete frame with its own constants, ticket counters and rays -- waves walk from a used-up frame to the next by themselves"),
+            "frames_per_launch": per_launch,
             "sharding": ("single GPU" if world == 1 else
                          f"{world} x interleaved {band}-row bands, every rank all {spp_rank} samples of its rows ((chunk, sample) work items) "
-                         f"+ RCCL gather of the packed bands to rank 0, one gather in flight" if by_rows else
+                         f"+ RCCL gather of the packed bands to rank 0, one message per peer per batch of {per_launch} steps, one gather in flight" if by_rows else
                          f"{world} x sample shards (every rank the full frame, {spp_rank} of the {spp_total} samples) + one RCCL sum-reduce to rank 0 after the last step"),
-            "exchange": (None if not multi else ("C-ABI bm_gather_frame / bm_reduce_frame over RCCL (csrc/comm.hip)" if getattr(gatherer or reducer, "comm", None) is not None
+            "exchange": (None if not multi else ("C-ABI bm_gather_frames / bm_reduce_frame over RCCL (csrc/comm.hip)" if getattr(gatherer or reducer, "comm", None) is not None
                                                      else "torch.distributed gather / reduce")),
-            "frame_mode": ("ordered sums (BM_HELPERS=0: helper lanes off)" if os.environ.get("BM_HELPERS") == "0" else
+            "frame_mode": ("ordered sums (helper lanes off)" if not plan["helpers"] else
                            "production default: shadow rays on helper lanes, radiance added with float atomics (like the reference's connect, kernel.cu:341-343); "
                            "multi-sample frames as (chunk, sample) work items; BM_FLAG_ORDERED frames -- what the parity suite compares bit for bit -- trace the same rays"),
+            "frame_plan": plan,
+            "env_overrides": overrides,  # the library's tuning knobs found in the environment ({}: the product's own rules)
             "camera": {"position": list(cam.position), "angles": [0.8, -0.5]},
             "world_build_s": round(build_s, 2),
         },
         "rays": {"nominal_per_step": nominal_rays_per_step, "actual_per_step_rank0": actual_rays / args.steps,
-                 "actual_Mrays_s_rank0_kernel": round(actual_rays / args.steps / avg_kernel_s / 1e6, 2)},
+                 "actual_Mrays_s_rank0_kernel": round(actual_rays / kernel_s / 1e6, 2)},
         "roofline": {
             "bound": "hbm",
             # what `achieved` is: SURVEY.md 8(d)'s ALGORITHMIC bytes -- the traffic of the REFERENCE's walk over the same rays
-            # (4 B per cell it would load + 64 B per brick test + 16 B per pixel) -- divided by this kernel's duration.  The
-            # kernel itself reads far less (one cube-field byte per STOP of the walk, index words only at candidates: see
-            # `traffic`, from the PMC counters); `limiter` names what actually bounds it on this workload.
-            "achieved_is": "reference-equivalent (algorithmic) bytes per launch / kernel duration",
-            **limiter_of(args.workload),
+            # (4 B per cell it would load + 64 B per brick test + 16 B per pixel) -- of the timed launches, divided by their
+            # duration (HIP events on the launch stream).  The kernel itself reads far less (one cube-field byte per STOP of the walk,
+            # index words only at candidates: see `traffic`, from the PMC counters); `limiter` names what actually bounds it.
+            "achieved_is": "reference-equivalent (algorithmic) bytes of the timed launches / their duration",
+            **limiter_of(args.workload, waves),
             "achieved": round(achieved_gbs, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
-            **counter_figures(args.workload, avg_kernel_s),
-            # (the plain instantiation; big frames -- 32000 tiles and more, scene.cpp frame_constants -- take the XCD-aware hand-out)
-            # (the plain instantiation <instrumented = false, XCD-aware hand-out, helper lanes>: big frames -- 32000 tiles and more, scene.cpp
-            # frame_constants -- take the XCD-aware hand-out; production frames run with helper lanes unless BM_FLAG_ORDERED / BM_HELPERS=0)
-            "kernel": "bm::trace_paths<false, %s, %s>" % (
-                "true" if (((W + 15) // 16) * ((state.local_rows + 15) // 16) >= 32000 and os.environ.get("BM_XCD_HANDOUT") != "0") or os.environ.get("BM_XCD_HANDOUT") == "1" else "false",
-                "false" if os.environ.get("BM_HELPERS") == "0" else "true"),
-            "kernel_ms_avg": round(float(np.mean(kernel_ms)), 4),
-            "algorithmic_bytes_per_launch": alg_bytes / args.steps,
+            **counter_figures(args.workload, kernel_ms_per_step * 1e-3, args.steps / len(timed)),
+            "kernel": kernel_name,
+            "waves_per_simd": waves,
+            "launches": len(timed), "frames_per_launch": [c for _, c in timed],
+            "kernel_ms_avg": round(float(np.mean(launch_ms)), 4),   # average duration of one timed LAUNCH of `kernel` (what rocprofv3 --stats reports for it)
+            "kernel_ms_per_step": round(kernel_ms_per_step, 4),
+            "algorithmic_bytes_per_launch": alg_bytes / len(timed),
+            "algorithmic_bytes_per_step": bytes_per_step,
             "bytes_per_actual_ray": round(alg_bytes / max(actual_rays, 1), 1),
-            "counts_per_launch": {k: v / args.steps for k, v in cnt.items()},
+            "counts_per_step": {k: v / args.steps for k, v in cnt.items()},
         },
     }
-    if pipeline > 1:
-        out["pipeline"] = {"streams": pipeline, "note": "consecutive steps on alternating streams, one accumulation buffer per stream; roofline uses "
-                           "each kernel's own HIP-event duration, which includes the time it shares the GPU with its neighbour",
-                           "frac_per_step": round(alg_bytes / args.steps / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)}
-    if pipelined is not None:
-        if "ms_per_step" in pipelined:
-            pipelined["frac_per_step"] = round(alg_bytes / args.steps / (pipelined["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-        out["pipelined"] = pipelined
-
+    if single is not None:
+        out["one_frame_per_launch"] = single
     if target4 is not None:
         out["north_star_4spp"] = target4
     if ranks_info is not None:
@@ -729,11 +718,16 @@ def cpu_baseline(W, H, max_bounces, G, cam):
     }
 
 
-def counter_figures(workload, kernel_s):
-    """pmc_traffic() plus the north-star's own measure: `frac_by_counters` = fabric-side bytes per launch (committed counter passes)
-    / THIS run's kernel duration / 8 TB/s -- next to `frac`, which prices the reference-equivalent bytes."""
+def counter_figures(workload, kernel_s_per_step, steps_per_launch=1.0):
+    """pmc_traffic() plus the north-star's own measure: `frac_by_counters` = fabric-side bytes per step (committed counter passes)
+    / THIS run's kernel time per step / 8 TB/s -- next to `frac`, which prices the reference-equivalent bytes.  `traffic` is per
+    launch, like `achieved`'s bytes (traffic_per_step x the steps of a timed launch)."""
     t = pmc_traffic(workload)
-    t["frac_by_counters"] = round(t["traffic"] / kernel_s / 1e9 / HBM_PEAK_GBS, 5) if t["traffic"] else None
+    per_step = t.pop("traffic_per_step")
+    t["traffic"] = int(per_step * steps_per_launch) if per_step else None
+    t["traffic_per_step"] = per_step
+    t["frac_by_counters"] = round(per_step / kernel_s_per_step / 1e9 / HBM_PEAK_GBS, 5) if per_step else None
+    t["traffic_age"] = traffic_age(workload)
     return t
 
 
@@ -745,25 +739,68 @@ def pmc_summary_path(workload):
     return None
 
 
-def limiter_of(workload):
-    """{"limiter": what bounds the kernel on this workload, "limiter_source": the committed counter passes the statement rests on}.
-    The statement is about the DEFAULT build and schedule as profiled in `limiter_source` (not re-derived by this run); it is
-    omitted when no PMC summary of the workload is committed (config 1, config 4: config 3's kernel on another frame size)."""
+def git_head():
+    """short commit of the tree bench.py runs from: git where there is a repository, else the note a gpurun snapshot carries (scratch/HEAD)"""
+    try:
+        r = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            return r.stdout.strip()
+    except (OSError, subprocess.SubprocessError):
+        pass
+    try:
+        return open(os.path.join(ROOT, "scratch", "HEAD")).read().strip() or None
+    except OSError:
+        return None
+
+
+def traffic_age(workload):
+    """How fresh the counter figures are: the commit the PMC summary was collected at (recorded in the file by
+    tools/profile_workload.py) against the commit this run is from -- a stale counter figure is visible in the line."""
     path = pmc_summary_path(workload)
-    if workload not in LIMITER or path is None or os.environ.get("BM_SCHEDULE"):
+    if path is None:
+        return None
+    try:
+        collected = json.load(open(path)).get("collected_at_commit")
+    except (OSError, ValueError):
+        collected = None
+    if not collected:  # summaries of earlier rounds do not say: the commit that put the file there
+        try:
+            r = subprocess.run(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, capture_output=True, text=True, timeout=10)
+            collected = r.stdout.strip() or None if r.returncode == 0 else None
+        except (OSError, subprocess.SubprocessError):
+            collected = None
+    head = git_head()
+    behind = None
+    if collected and head:
+        try:
+            r = subprocess.run(["git", "rev-list", "--count", f"{collected}..{head}"], cwd=ROOT, capture_output=True, text=True, timeout=10)
+            behind = int(r.stdout.strip()) if r.returncode == 0 and r.stdout.strip() else None
+        except (OSError, subprocess.SubprocessError, ValueError):
+            behind = None
+    return {"summary": f"profiles/{os.path.basename(path)}", "collected_at_commit": collected, "head": head, "commits_behind_head": behind}
+
+
+def limiter_of(workload, waves_per_simd=None):
+    """{"limiter": what bounds the kernel on this workload, "limiter_source": the committed counter passes the statement rests on}.
+    The statement is about the DEFAULT build and schedule as profiled in `limiter_source` (not re-derived by this run), with the
+    occupancy filled in from the library (bm_trace_waves_per_simd of the instantiation that ran); it is omitted when no PMC summary
+    of the workload is committed (config 1, config 4: config 3's kernel on another frame size)."""
+    path = pmc_summary_path(workload)
+    if workload not in LIMITER or path is None:
         return {"limiter": None, "limiter_source": None}
-    return {"limiter": LIMITER[workload], "limiter_source": f"profiles/{os.path.basename(path)} + DESIGN.md 4 (default build, default schedule)"}
+    return {"limiter": LIMITER[workload].format(waves=waves_per_simd if waves_per_simd else "?"),
+            "limiter_source": f"profiles/{os.path.basename(path)} + DESIGN.md 4 (default build, default schedule)"}
 
 
 def pmc_traffic(workload):
-    """{"traffic": fabric-side bytes per launch, "valu_lanes": lanes active per VALU instruction, "valu_insts": wave-level VALU
-    instructions per launch, "traffic_source": where they come from}.  The counters are NOT collected by this run (rocprofv3 PMC
+    """{"traffic_per_step": fabric-side bytes per step (frame), "valu_lanes": lanes active per VALU instruction, "valu_insts": wave-level VALU
+    instructions per step, "traffic_source": where they come from}.  The counters are NOT collected by this run (rocprofv3 PMC
     needs its own passes, tools/profile_workload.py): the figures are read from the committed summary of the same workload and
-    kernel, and the source is named in the line.  FETCH_SIZE and WRITE_SIZE are KiB.  On gfx950 FETCH_SIZE = read requests x 64 B:
-    the guide's x2 applies to full-line coalesced streams only; every read of this kernel is a single 64-byte sector request, for
-    which FETCH_SIZE is exact (profiles/r03_fetch_calibration.txt, measured with tools/ubench/fetch_calib.hip on 1-byte / 4-byte /
-    64-byte gathers) -- factor 1.0.  Infinity-Cache hits are included."""
-    none = {"traffic": None, "valu_lanes": None, "valu_insts": None, "traffic_source": None}
+    kernel -- per launch there, divided by the summary's frames per launch -- and the source is named in the line.  FETCH_SIZE and
+    WRITE_SIZE are KiB.  On gfx950 FETCH_SIZE = read requests x 64 B: the guide's x2 applies to full-line coalesced streams only;
+    every read of this kernel is a single 64-byte sector request, for which FETCH_SIZE is exact (profiles/r03_fetch_calibration.txt,
+    measured with tools/ubench/fetch_calib.hip on 1-byte / 4-byte / 64-byte gathers) -- factor 1.0.  Infinity-Cache hits are included."""
+    none = {"traffic_per_step": None, "valu_lanes": None, "valu_insts": None, "traffic_source": None}
     path = pmc_summary_path(workload)
     if path is None:
         return none
@@ -772,10 +809,11 @@ def pmc_traffic(workload):
             d = json.load(f)
         if d.get("workload") != workload:
             return none
+        frames = float(d.get("frames_per_launch", 1) or 1)
         lanes = d["SQ_THREAD_CYCLES_VALU"] / d["SQ_ACTIVE_INST_VALU"] if d.get("SQ_ACTIVE_INST_VALU") else None
-        return {"traffic": int((1.0 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024),
+        return {"traffic_per_step": int((1.0 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024 / frames),
                 "valu_lanes": round(lanes, 2) if lanes else None,
-                "valu_insts": int(d["SQ_INSTS_VALU"]) if d.get("SQ_INSTS_VALU") else None,
+                "valu_insts": int(d["SQ_INSTS_VALU"] / frames) if d.get("SQ_INSTS_VALU") else None,
                 "traffic_source": f"profiles/{os.path.basename(path)} (separate rocprofv3 --pmc passes of this workload, not this run)"}
     except (OSError, KeyError, ValueError):
         return none

@@ -135,6 +135,7 @@ SIGNATURES = {
     "bm_comm_available": (_i, []),
     "bm_debug_division_magic": (_i, [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "bm_gather_frame": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "bm_gather_frames": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "bm_reduce_frame": (_i, [_vp, _vp, _vp, C.c_int64, _i, _vp]),
     "bm_probe_streams": (_i, [_i, _i, C.POINTER(_vp)]),
     "bm_release_streams": (None, [_i, C.POINTER(_vp)]),

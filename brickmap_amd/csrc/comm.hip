@@ -97,15 +97,25 @@ int shard_rows(int height, int band_rows, int rank, int world) {
 }
 
 // frame row y <- packed row ((y / band) / world) * band + y % band of rank (y / band) % world; the root's own rows come from
-// its packed buffer, everybody else's from the stacked receive buffer (max_rows rows per rank)
+// its packed buffer, everybody else's from the stacked receive buffer.  blockIdx.y = frame of the batch (bm_gather_frames): every
+// rank's packed buffer holds its rows of frame 0, then of frame 1, ... (rows_r x width each), and the stacked buffer holds rank r's
+// whole batch at r * count * max_rows * width -- as it was sent, tightly packed.
+__device__ __forceinline__ int rows_of_rank(int height, int band_rows, int rank, int world) { // bm_local_rows in closed form
+	const int full_bands = height / band_rows, tail = height % band_rows;
+	int rows = rank < full_bands ? ((full_bands - 1 - rank) / world + 1) * band_rows : 0;
+	if (tail && full_bands % world == rank) rows += tail;
+	return rows;
+}
 __global__ void assemble_frame(const float4* __restrict__ own, const float4* __restrict__ stacked, float4* __restrict__ frame, int height, int width, int band_rows,
-							   int world, int me, int max_rows) {
+							   int world, int me, int max_rows, int count) {
 	const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
 	if (i >= static_cast<long long>(height) * width) return;
+	const int k = static_cast<int>(blockIdx.y);
 	const int y = static_cast<int>(i / width), x = static_cast<int>(i - static_cast<long long>(y) * width);
 	const int band = y / band_rows, r = band % world, lrow = (band / world) * band_rows + y % band_rows;
-	const float4* src = r == me ? own : stacked + static_cast<size_t>(r) * max_rows * width;
-	frame[i] = src[static_cast<size_t>(lrow) * width + x];
+	const size_t rows_r = static_cast<size_t>(rows_of_rank(height, band_rows, r, world));
+	const float4* src = (r == me ? own : stacked + static_cast<size_t>(r) * count * max_rows * width) + static_cast<size_t>(k) * rows_r * width;
+	frame[static_cast<size_t>(k) * height * width + i] = src[static_cast<size_t>(lrow) * width + x];
 }
 
 // bm_probe_streams: one wave that does nothing for `ticks` of the constant 100 MHz clock
@@ -191,17 +201,22 @@ int bm_comm_info(bm_comm* c, int* rank, int* world) {
 }
 
 int bm_gather_frame(bm_comm* c, const float* packed_dev, float* frame_dev, int height, int width, int band_rows, int root, void* hip_stream) {
+	return bm_gather_frames(c, packed_dev, frame_dev, 1, height, width, band_rows, root, hip_stream);
+}
+
+int bm_gather_frames(bm_comm* c, const float* packed_dev, float* frames_dev, int count, int height, int width, int band_rows, int root, void* hip_stream) {
 	if (!c) { set_error("null communicator"); return BM_EINVAL; }
-	if (!packed_dev || height <= 0 || width <= 0 || band_rows <= 0 || root < 0 || root >= c->world) { set_error("bad argument"); return BM_EINVAL; }
-	if (c->rank == root && !frame_dev) { set_error("the root needs a frame buffer"); return BM_EINVAL; }
+	if (!packed_dev || count < 1 || count > 256 || height <= 0 || width <= 0 || band_rows <= 0 || root < 0 || root >= c->world) { set_error("bad argument"); return BM_EINVAL; }
+	if (c->rank == root && !frames_dev) { set_error("the root needs a frame buffer"); return BM_EINVAL; }
 	bm::Rccl* R = bm::rccl();
 	hipStream_t stream = static_cast<hipStream_t>(hip_stream);
 	BM_HIP(hipSetDevice(c->device));
 	int max_rows = 0;
 	for (int r = 0; r < c->world; ++r) { const int n = bm::shard_rows(height, band_rows, r, c->world); if (n > max_rows) max_rows = n; }
 	const size_t row_floats = static_cast<size_t>(width) * 4;
+	const size_t slot_floats = static_cast<size_t>(count) * max_rows * row_floats; // one rank's batch in the stacked buffer
 	if (c->rank == root && c->world > 1) {
-		const size_t need = static_cast<size_t>(c->world) * max_rows * row_floats * sizeof(float);
+		const size_t need = static_cast<size_t>(c->world) * slot_floats * sizeof(float);
 		if (c->stacked_bytes < need) {
 			if (c->stacked) { BM_HIP(hipStreamSynchronize(stream)); BM_HIP(hipFree(c->stacked)); c->stacked = nullptr; c->stacked_bytes = 0; }
 			BM_HIP(hipMalloc(reinterpret_cast<void**>(&c->stacked), need));
@@ -209,18 +224,20 @@ int bm_gather_frame(bm_comm* c, const float* packed_dev, float* frame_dev, int h
 		}
 	}
 	if (c->world > 1) {
+		// ONE message per peer for the whole batch (its rows of frame 0, of frame 1, ...: the packed buffers of a batch are one
+		// allocation), all of them in one group: every peer's bands travel on its own xGMI link into the root.
 		// (an error inside the group must not leave RCCL in group mode: the group is always closed, the first error is reported)
 		BM_NCCL(R->GroupStart());
 		ncclResult_t first = ncclSuccess;
 		if (c->rank == root) {
 			for (int r = 0; r < c->world && first == ncclSuccess; ++r) {
 				if (r == root) continue;
-				const size_t count = static_cast<size_t>(bm::shard_rows(height, band_rows, r, c->world)) * row_floats;
-				if (count) first = R->Recv(c->stacked + static_cast<size_t>(r) * max_rows * row_floats, count, ncclFloat, r, c->comm, stream);
+				const size_t n = static_cast<size_t>(count) * bm::shard_rows(height, band_rows, r, c->world) * row_floats;
+				if (n) first = R->Recv(c->stacked + static_cast<size_t>(r) * slot_floats, n, ncclFloat, r, c->comm, stream);
 			}
 		} else {
-			const size_t count = static_cast<size_t>(bm::shard_rows(height, band_rows, c->rank, c->world)) * row_floats;
-			if (count) first = R->Send(packed_dev, count, ncclFloat, root, c->comm, stream);
+			const size_t n = static_cast<size_t>(count) * bm::shard_rows(height, band_rows, c->rank, c->world) * row_floats;
+			if (n) first = R->Send(packed_dev, n, ncclFloat, root, c->comm, stream);
 		}
 		const ncclResult_t closed = R->GroupEnd();
 		if (first != ncclSuccess) return bm::nccl_fail(first, "ncclSend / ncclRecv of the packed row bands");
@@ -228,8 +245,9 @@ int bm_gather_frame(bm_comm* c, const float* packed_dev, float* frame_dev, int h
 	}
 	if (c->rank == root) {
 		const long long n = static_cast<long long>(height) * width;
-		hipLaunchKernelGGL(bm::assemble_frame, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const float4*>(packed_dev),
-						   reinterpret_cast<const float4*>(c->stacked), reinterpret_cast<float4*>(frame_dev), height, width, band_rows, c->world, c->rank, max_rows);
+		hipLaunchKernelGGL(bm::assemble_frame, dim3(static_cast<unsigned>((n + 255) / 256), static_cast<unsigned>(count)), dim3(256), 0, stream,
+						   reinterpret_cast<const float4*>(packed_dev), reinterpret_cast<const float4*>(c->stacked), reinterpret_cast<float4*>(frames_dev), height, width,
+						   band_rows, c->world, c->rank, max_rows, count);
 		BM_HIP(hipGetLastError());
 	}
 	return 0;
@@ -309,7 +327,7 @@ int bm_debug_assemble_frame(int device, const float* own_packed_dev, const float
 	const long long n = static_cast<long long>(height) * width;
 	hipLaunchKernelGGL(bm::assemble_frame, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
 					   reinterpret_cast<const float4*>(own_packed_dev), reinterpret_cast<const float4*>(stacked_dev), reinterpret_cast<float4*>(frame_dev), height, width,
-					   band_rows, world, me, max_rows);
+					   band_rows, world, me, max_rows, 1);
 	BM_HIP(hipGetLastError());
 	return 0;
 }

@@ -799,7 +799,13 @@ void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameCo
 	int per_cu = trace_blocks_per_cu(instrumented, xcd, help, ring); // what THIS instantiation keeps resident
 	if (blocks_per_cu_cap > 0 && per_cu > blocks_per_cu_cap) per_cu = blocks_per_cu_cap;
 	const long long resident_blocks = static_cast<long long>(compute_units) * per_cu;
-	long long blocks = (chunks + 15) / 16; // never more workgroups than 64-pixel groups
+	// never more waves than a frame has 64-item groups: an item is a pixel, or ONE sample of a pixel with (chunk, sample) items -- a
+	// 1/8 shard of a 1080p frame at 8 spp is 276 480 pixels but 2.2 M items, and sizing its launch by pixels left 40 % of the
+	// GPU's wave slots empty (1080 of 1792 workgroups: 1.16 -> 0.95 ms per shard step).  A launch of several frames may start a
+	// second frame's worth of waves: those that find the first frame's counters used up go straight on to the next one.
+	const long long items = chunks * 16 * ((fc.flags & 4u /* BM_FLAG_SAMPLE_ITEMS */) ? (fc.spp > 0 ? fc.spp : 1) : 1);
+	long long blocks = (items + 255) / 256;
+	if (ring) blocks *= 2;
 	if (blocks > resident_blocks) blocks = resident_blocks;
 	const dim3 grid(static_cast<unsigned>(blocks)), block(256);
 #ifdef BM_PHASE_TIMING

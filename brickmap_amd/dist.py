@@ -78,6 +78,15 @@ class Comm:
         self._check(self._L.bm_gather_frame(self.handle, C.c_void_p(packed.data_ptr()), C.c_void_p(frame.data_ptr()) if frame is not None else None,
                                             int(height), int(width), int(band_rows), int(root), C.c_void_p(stream)))
 
+    def gather_frames(self, packed, frames, count, height, width, band_rows, root=0, stream=None):
+        """bm_gather_frames: a batch -- `packed` = [count, local_rows, width, 4] (one allocation, what ONE bm_render_frames launch filled),
+        `frames` = [count, height, width, 4] on the root; one message per peer for the whole batch."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream(packed.device).cuda_stream
+        self._check(self._L.bm_gather_frames(self.handle, C.c_void_p(packed.data_ptr()), C.c_void_p(frames.data_ptr()) if frames is not None else None,
+                                             int(count), int(height), int(width), int(band_rows), int(root), C.c_void_p(stream)))
+
     def reduce_frame(self, src, dst, root=0, stream=None):
         import torch
         if stream is None:
@@ -233,21 +242,26 @@ class FrameGatherer:
     assembled [height, W, C] frame (None elsewhere; the returned tensor is reused by the next finish()).  At most one
     gather is in flight.  The root receives every peer's packed bands into one stacked buffer and assembles the frame
     with ONE precomputed permutation gather (index_select), not one scatter per peer.
+    frames > 1: the unit of exchange is a BATCH of that many frames -- what a rank rendered with one Scene.render_frames launch
+    (the frame ring): start() takes [frames, local_rows, W, C] (or a list of that many [local_rows, W, C] tensors), every peer sends
+    its whole batch as ONE message (bm_gather_frames), finish() returns [frames, height, W, C].
     force_collective: issue the collective also when the group has a single rank (the 1-rank RCCL dry run of the tests:
     communicator, device buffers, asynchronous work handle -- everything except a second rank)."""
 
     def __init__(self, height, width, channels=4, band_rows=DEFAULT_BAND_ROWS, dtype=None, device=None, group=None, dst=0, force_collective=False,
-                 side_stream=None):
+                 side_stream=None, frames=1):
         import torch
         import torch.distributed as dist
         self.height, self.band_rows, self.group, self.dst = height, band_rows, group, dst
+        self.frames = int(frames)
+        assert 1 <= self.frames <= 256
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         self.counts = [len(shard_rows(height, band_rows, r, self.world)) for r in range(self.world)]
         self.out_device = torch.device(device) if device is not None else torch.device("cpu")
         dtype = dtype or torch.float32
-        # the exchange behind the C-ABI (bm_gather_frame) where it applies: it runs on a side stream, behind a snapshot of the packed
+        # the exchange behind the C-ABI (bm_gather_frames) where it applies: it runs on a side stream, behind a snapshot of the packed
         # rows and beside the next frame.  (Made first: the buffers below live on the device with it, on the host for gloo.)
         self.comm = None
         if _use_capi(self.collective, group, self.out_device) and channels == 4 and dtype == torch.float32:
@@ -255,45 +269,69 @@ class FrameGatherer:
         # gloo (CPU tests / single-GPU smoke runs) has no device gather: stage through host memory there
         self.stage_on_cpu = self.collective and self.comm is None and dist.get_backend(group) == "gloo"
         buf_device = torch.device("cpu") if self.stage_on_cpu else self.out_device
-        shape = (max(self.counts), width, channels)
-        self.send = torch.zeros(shape, dtype=dtype, device=buf_device)
-        root = self.rank == dst
         torch_path = self.comm is None  # (with the C-ABI exchange the root's receive buffer belongs to the communicator)
-        self.recv_all = torch.empty((self.world,) + shape, dtype=dtype, device=buf_device) if root and torch_path else None
+        max_rows = max(self.counts)
+        # the batch as it is sent: tightly packed for the C-ABI exchange (one message of frames x local_rows rows), padded to the
+        # largest shard for torch.distributed's equal-sized gather
+        self.send = torch.zeros((self.frames, max_rows if torch_path else self.counts[self.rank], width, channels), dtype=dtype, device=buf_device)
+        root = self.rank == dst
+        self.recv_all = torch.empty((self.world,) + tuple(self.send.shape), dtype=dtype, device=buf_device) if root and torch_path else None
         self.recv = [self.recv_all[r] for r in range(self.world)] if root and torch_path else None
-        self.index = torch.as_tensor(assembly_index(height, band_rows, self.world), device=buf_device, dtype=torch.long) if root and torch_path else None
-        self.out = torch.empty((height, width, channels), dtype=dtype, device=buf_device) if root else None
+        self.index = None
+        if root and torch_path:  # frame k, row y <- stacked row (its rank) * frames * max_rows + k * max_rows + (its packed row)
+            base = assembly_index(height, band_rows, self.world)
+            r_of, l_of = base // max_rows, base % max_rows
+            idx = np.concatenate([r_of * self.frames * max_rows + k * max_rows + l_of for k in range(self.frames)])
+            self.index = torch.as_tensor(idx, device=buf_device, dtype=torch.long)
+        self.out = torch.empty((self.frames, height, width, channels), dtype=dtype, device=buf_device) if root else None
         self.work = None
         self.local = None
         self.width = width
         if self.comm is not None:
             # side_stream: HIP maps streams onto a few hardware queues, and a queue runs its packets in order -- a gather that waits for
             # its frame at the head of a queue holds up whatever another stream put behind it there (the NEXT frame, if the render
-            # stream shares that queue: measured, the two-stream pipeline of bench.py then ran no faster than one stream).  A caller
-            # that pipelines frames over several streams passes a stream it has probed to run beside them (bench.py pick_streams).
+            # stream shares that queue).  A caller that pipelines frames over several streams passes a stream it has probed to run
+            # beside them (bm_probe_streams).
             self.side = side_stream if side_stream is not None else torch.cuda.Stream(device=self.out_device)
             self.snap = torch.cuda.Event()
             self.pending = False
+
+    def _snapshot(self, local):
+        """copy the caller's packed rows (one frame, a batch tensor, or a list of frames) into the send buffer"""
+        rows = self.counts[self.rank]
+        if isinstance(local, (list, tuple)):
+            assert len(local) == self.frames
+            for k, t in enumerate(local):
+                assert t.shape[0] == rows
+                self.send[k, :rows].copy_(t)
+        elif local.dim() == self.send.dim():
+            assert local.shape[0] == self.frames and local.shape[1] == rows
+            self.send[:, :rows].copy_(local)
+        else:
+            assert self.frames == 1 and local.shape[0] == rows
+            self.send[0, :rows].copy_(local)
+
+    def _result(self, out):
+        return out if self.frames > 1 else out[0]
 
     def start(self, local):
         import torch
         import torch.distributed as dist
         assert self.work is None and self.local is None, "finish() the previous gather first"
-        assert local.shape[0] == self.counts[self.rank]
         if not self.collective:
-            self.local = local
+            self.local = torch.stack(list(local)) if isinstance(local, (list, tuple)) else local
             return
         if self.comm is not None:
             assert not self.pending, "finish() the previous gather first"
             cur = torch.cuda.current_stream(self.out_device)
             cur.wait_stream(self.side)  # the previous gather has read `send` (whichever stream its finish() was called on)
-            self.send[: local.shape[0]].copy_(local)  # snapshot: the caller may keep accumulating into `local`
+            self._snapshot(local)  # the caller may keep accumulating into `local`
             self.snap.record(cur)
             self.side.wait_event(self.snap)
-            self.comm.gather_frame(self.send, self.out, self.height, self.width, self.band_rows, root=self.dst, stream=self.side.cuda_stream)
+            self.comm.gather_frames(self.send, self.out, self.frames, self.height, self.width, self.band_rows, root=self.dst, stream=self.side.cuda_stream)
             self.pending = True
             return
-        self.send[: local.shape[0]].copy_(local)  # snapshot: the caller may keep accumulating into `local`
+        self._snapshot(local)  # the caller may keep accumulating into `local`
         self.work = dist.gather(self.send, gather_list=self.recv, dst=self.dst, group=self.group, async_op=True)
 
     def finish(self, wait=True):
@@ -309,15 +347,16 @@ class FrameGatherer:
             if wait:
                 torch.cuda.current_stream(self.out_device).wait_stream(self.side)  # like Work.wait(): the current stream, not the host
             self.pending = False
-            return self.out if self.rank == self.dst else None
+            return self._result(self.out) if self.rank == self.dst else None
         if self.work is None:
             return None
         self.work.wait()
         self.work = None
         if self.rank != self.dst:
             return None
-        torch.index_select(self.recv_all.view((-1,) + tuple(self.send.shape[1:])), 0, self.index, out=self.out)
-        return self.out if self.out.device == self.out_device else self.out.to(self.out_device)
+        torch.index_select(self.recv_all.view((-1,) + tuple(self.send.shape[2:])), 0, self.index, out=self.out.view((-1,) + tuple(self.send.shape[2:])))
+        out = self._result(self.out)
+        return out if out.device == self.out_device else out.to(self.out_device)
 
 
 class FrameReducer:

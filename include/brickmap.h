@@ -294,6 +294,11 @@ BM_API int bm_comm_available(void);
  * does not wait.  The row-to-rank map is that of bm_frame_params: row y belongs to rank (y / band_rows) % world. */
 BM_API int bm_gather_frame(bm_comm* comm, const float* packed_dev, float* frame_dev, int height, int width, int band_rows, int root,
                            void* hip_stream);
+/* The same exchange for a batch of `count` (1 ... 256) frames -- what a rank rendered with ONE bm_render_frames launch into ONE
+ * allocation: packed_dev = count x bm_local_rows x width float4 (frame 0's rows, then frame 1's, ...), frames_dev = count x height x
+ * width float4 on the root.  One ncclSend per peer for the whole batch, one group, one assembly kernel. */
+BM_API int bm_gather_frames(bm_comm* comm, const float* packed_dev, float* frames_dev, int count, int height, int width, int band_rows,
+                            int root, void* hip_stream);
 /* sample-sharded frames (every rank renders the whole frame with its own sample_base slice): ncclReduce(sum) to the root */
 BM_API int bm_reduce_frame(bm_comm* comm, const float* in_dev, float* out_dev, int64_t n_floats, int root, void* hip_stream);
 /* all ranks have reached this point (an all-reduce of one word, then the host waits for the stream) */

@@ -47,6 +47,23 @@ def main():
         print("PIPE_OK", world)
     else:
         assert first is None and second is None
+    # batches (what a rank renders with one frame-ring launch): three frames per exchange, as one tensor and as a list of frames
+    gb = bdist.FrameGatherer(H, W, band_rows=band, device="cpu", frames=3)
+    batch = torch.stack([local, local * 3, local * 5])
+    gb.start(batch)
+    got_b = gb.finish()
+    got_b = got_b.clone() if got_b is not None else None
+    gb.start([local * 7, local, local * 2])
+    got_l = gb.finish()
+    if rank == 0:
+        assert tuple(got_b.shape) == (3, H, W, 4)
+        for k, f in enumerate((1, 3, 5)):
+            assert np.array_equal(got_b[k].numpy(), want * f)
+        for k, f in enumerate((7, 1, 2)):
+            assert np.array_equal(got_l[k].numpy(), want * f)
+        print("BATCH_OK", world)
+    else:
+        assert got_b is None and got_l is None
     # sample sharding: every rank renders the full frame with its own sample indices; the frames are summed on rank 0
     mine = np.zeros((H, W, 4), np.float32)
     w.render(cam, oracle.make_frame(W, H, spp=2, sample_base=2 * rank), accum=mine, want_dbg=False)

@@ -45,6 +45,22 @@ def main():
             scene.render(cam, bm.FrameParams(W, H, spp=2, max_bounces=3, flags=bm.BM_FLAG_ORDERED), want)
         torch.cuda.synchronize()
         assert torch.equal(frame.view(torch.int32), want.view(torch.int32)), "gathered frame differs from the unsharded render"
+    # a batch: three frames (own sample_base each) rendered by ONE frame-ring launch into one allocation, exchanged as one message
+    # per peer (bm_gather_frames) -- each gathered frame is the unsharded frame bit for bit
+    K = 3
+    rows = state.local_rows
+    packed = torch.zeros((K, rows, W, 4), dtype=torch.float32, device="cuda:0")
+    ps = [bm.FrameParams(W, H, spp=2, sample_base=10 + 2 * k, max_bounces=3, band_rows=band, shard_rank=rank, shard_count=world, flags=bm.BM_FLAG_ORDERED) for k in range(K)]
+    scene.render_frames(cam, ps, [packed[k] for k in range(K)])
+    frames = torch.full((K, H, W, 4), float("nan"), dtype=torch.float32, device="cuda:0") if rank == root else None
+    comm.gather_frames(packed, frames, K, H, W, band, root=root)
+    torch.cuda.synchronize()
+    if rank == root:
+        for k in range(K):
+            want = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+            scene.render(cam, bm.FrameParams(W, H, spp=2, sample_base=10 + 2 * k, max_bounces=3, flags=bm.BM_FLAG_ORDERED), want)
+            torch.cuda.synchronize()
+            assert torch.equal(frames[k].view(torch.int32), want.view(torch.int32)), f"frame {k} of the gathered batch differs from the unsharded render"
     # the sample decomposition's exchange: every rank contributes rank + 1
     src = torch.full((H, W, 4), float(rank + 1), dtype=torch.float32, device="cuda:0")
     dst = torch.zeros_like(src) if rank == root else None

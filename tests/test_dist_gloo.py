@@ -24,4 +24,4 @@ def test_sharded_frame_gathers_to_the_single_rank_frame(world, orc):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert f"DIST_OK {world}" in r.stdout and f"PIPE_OK {world}" in r.stdout and f"SAMPLES_OK {world}" in r.stdout
+    assert f"DIST_OK {world}" in r.stdout and f"PIPE_OK {world}" in r.stdout and f"SAMPLES_OK {world}" in r.stdout and f"BATCH_OK {world}" in r.stdout

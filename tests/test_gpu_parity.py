@@ -1119,8 +1119,9 @@ def test_sample_items_digest_matches_oracle(bm, orc, torch_cuda, scene256, world
 
 
 def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda, tmp_path):
-    """`bench.py --gpus 2` end to end -- row-band shards with (chunk, sample) work items, pipelined gather to rank 0 (the driver's
-    command line: every rank's frames overlap on two streams; then on one stream; then the sample decomposition),
+    """`bench.py --gpus 2` end to end -- row-band shards with (chunk, sample) work items, steps issued as frame-ring launches with one
+    gather per batch to rank 0 (the driver's command line; then two steps per launch, so that the timed region holds a full and a
+    short batch; then one launch per step; then the sample decomposition),
     the gathered / reduced frames compared with one GPU rendering everything (--verify),
     max-over-ranks timing, one JSON line -- with both ranks on this GPU and gloo instead of RCCL (BM_BENCH_SHARE_GPU=1).
     The 8-GPU run itself is the driver's; this pins the code path it takes."""
@@ -1133,7 +1134,8 @@ def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda, tmp_path):
     from conftest import build_fake_rccl
     fake = build_fake_rccl(tmp_path)
     # the last two runs take the C-ABI exchange (bm_gather_frame / bm_reduce_frame, what an RCCL group uses) over the stand-in transport
-    for extra, capi in (([], False), (["--pipeline", "1"], False), (["--decomposition", "samples"], False), ([], True), (["--decomposition", "samples"], True)):
+    for extra, capi in (([], False), (["--frames-per-launch", "2"], False), (["--frames-per-launch", "1"], False), (["--decomposition", "samples"], False), ([], True),
+                        (["--frames-per-launch", "2"], True), (["--decomposition", "samples"], True)):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--workload", "config1", "--verify"] + extra
         env = dict(os.environ, BM_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
@@ -1147,7 +1149,8 @@ def test_bench_multi_rank_path_on_one_gpu(bm, torch_cuda, tmp_path):
         assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "strong"
         assert out["config"]["spp_per_step"] == 8 and "roofline" in out and "cpu_baseline" not in out
         assert out["verified_against_single_gpu"]["frames"] == 5 and out["verified_against_single_gpu"]["max_rel_err"] < 1e-5
-        assert ("pipeline" in out) == ("--pipeline" not in extra) and out.get("pipeline", {"streams": 2})["streams"] == 2
+        want_f = int(extra[1]) if "--frames-per-launch" in extra else 3  # (default: min(5, steps) per launch and per exchange; samples: all steps)
+        assert out["config"]["frames_per_launch"] == want_f and sum(out["roofline"]["frames_per_launch"]) == 3
         assert ("C-ABI" in out["config"]["exchange"]) == capi
         port += 1
 

@@ -25,7 +25,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
-KERNEL = os.environ.get("BM_PROFILE_KERNEL", "trace_paths<false,")  # (both hand-out instantiations: <false, false> and, on big frames, <false, true>)
+KERNEL = os.environ.get("BM_PROFILE_KERNEL", "trace_paths<false,")  # (every production instantiation: hand-out, helper lanes, frame ring)
+PMC_FRAMES = 4  # the counter passes run `--steps 4 --warmup 4`: on resident workloads two launches of four frames each (the frame ring), same kernel
 FETCH_FACTOR = 1.0  # profiles/r03_fetch_calibration.txt: single-sector requests are counted at their true 64 bytes
 PMC_SETS = [
     "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_ACTIVE_INST_ANY",
@@ -65,7 +66,7 @@ def main():
     # the TIMED launches alone, from the trace of the same run: the stats' average also covers the warm-up launches (on a streaming
     # workload those include the fill of the brick pools), the roofline prices the timed ones
     timed_ms = None
-    n_timed = int((extra + steps)[(extra + steps).index("--steps") + 1])
+    n_timed = int(bench_json["roofline"].get("launches") or (extra + steps)[(extra + steps).index("--steps") + 1])  # timed LAUNCHES (a launch may hold several steps)
     for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         rows = [r_ for r_ in csv.DictReader(open(f)) if KERNEL in r_.get("Kernel_Name", "")]
         rows.sort(key=lambda r_: int(r_["Start_Timestamp"]))
@@ -85,23 +86,29 @@ def main():
         d = f"/tmp/pmc_{tag}_{workload}_{i}"
         shutil.rmtree(d, ignore_errors=True)
         subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + group.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--"] + bench +
-                       ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, cwd="/tmp", env=env)
+                       ["--steps", str(PMC_FRAMES), "--warmup", str(PMC_FRAMES), "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, cwd="/tmp", env=env)
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(f)):
                 if KERNEL in row["Kernel_Name"]:
                     tot[row["Counter_Name"]] += float(row["Counter_Value"])
                     n[row["Counter_Name"]] += 1
-    s = {"workload": workload, "per": f"launch of bm::{KERNEL} (average over the {max(n.values()) if n else 0} launches of a short bench run, warm-up and streaming fill included)"}
+    # frames per launch of those runs: what bench.py issues by default for this workload (resident: all four steps in one launch; streaming: one)
+    pmc_frames = PMC_FRAMES if bench_json["config"].get("frames_per_launch", 1) > 1 else 1
+    sys.path.insert(0, ROOT)
+    import bench as bench_mod
+    s = {"workload": workload, "frames_per_launch": pmc_frames, "collected_at_commit": bench_mod.git_head(),
+         "per": f"launch of bm::{KERNEL} of {pmc_frames} frame(s) (average over the {max(n.values()) if n else 0} launches of a short bench run, warm-up and streaming fill included)"}
     for c in sorted(tot):
         s[c + ("_KiB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")] = tot[c] / n[c]
     if "FETCH_SIZE_KiB" in s and "WRITE_SIZE_KiB" in s:
         hbm = (FETCH_FACTOR * s["FETCH_SIZE_KiB"] + s["WRITE_SIZE_KiB"]) * 1024
-        ms = bench_json["roofline"]["kernel_ms_avg"]
+        ms = bench_json["roofline"]["kernel_ms_per_step"] * pmc_frames  # duration of a launch of the counter passes' shape, at this run's rate
         s["derived"] = {
             "fabric_bytes_per_launch (1.0 x FETCH + WRITE; sector requests, MALL hits included)": hbm,
             "sector_requests_per_s_G": (s["TCC_MISS"] / (ms * 1e-3) / 1e9) if s.get("TCC_MISS") else None,
             "frac_of_measured_random_sector_ceiling (48 G requests/s)": (s["TCC_MISS"] / (ms * 1e-3) / 48e9) if s.get("TCC_MISS") else None,
-            "kernel_ms_avg (bench, HIP events)": ms,
+            "kernel_ms_per_step (bench, HIP events)": bench_json["roofline"]["kernel_ms_per_step"],
+            "kernel_ms_avg (bench, HIP events, per timed launch)": bench_json["roofline"]["kernel_ms_avg"],
             "kernel_ms_avg (rocprofv3 --stats)": kernel_avg_ns / 1e6 if kernel_avg_ns else None,
             "kernel_ms_avg (rocprofv3 kernel trace, the timed launches only)": timed_ms,
             "hbm_GBps": hbm / (ms * 1e-3) / 1e9,
@@ -118,17 +125,15 @@ def main():
     #    exactly what bench.py does with the committed file: the same function, pointed at the new file
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     shutil.copy(os.path.join(OUT, f"{tag}_pmc_summary_{workload}.json"), os.path.join(ROOT, "profiles", f"{tag}_pmc_summary_{workload}.json"))
-    sys.path.insert(0, ROOT)
-    import bench as bench_mod
     assert bench_mod.PROFILE_ROUNDS[0] == tag, f"bench.py PROFILE_ROUNDS must start with {tag}"
     rf = bench_json["roofline"]
-    rf.update(bench_mod.counter_figures(workload, rf["kernel_ms_avg"] * 1e-3))
+    rf.update(bench_mod.counter_figures(workload, rf["kernel_ms_per_step"] * 1e-3, sum(rf["frames_per_launch"]) / len(rf["frames_per_launch"])))
     json.dump(bench_json, open(os.path.join(OUT, f"{tag}_bench_{workload}.json"), "w"), indent=1)
     print("bench line:", bench_json["value"], bench_json["unit"], bench_json["ms_per_step"], "ms/step, frac", rf["frac"], "frac_by_counters", rf.get("frac_by_counters"),
           "lanes", rf.get("valu_lanes"))
     if "derived" in s:
-        want = int((FETCH_FACTOR * s["FETCH_SIZE_KiB"] + s["WRITE_SIZE_KiB"]) * 1024)
-        assert rf["traffic"] == want and f"{tag}_pmc_summary_{workload}.json" in rf["traffic_source"], (rf["traffic"], want, rf["traffic_source"])
+        want = int((FETCH_FACTOR * s["FETCH_SIZE_KiB"] + s["WRITE_SIZE_KiB"]) * 1024 / pmc_frames)
+        assert rf["traffic_per_step"] == want and f"{tag}_pmc_summary_{workload}.json" in rf["traffic_source"], (rf["traffic"], want, rf["traffic_source"])
 
 if __name__ == "__main__":
     main()
