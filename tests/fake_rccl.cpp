@@ -11,6 +11,7 @@
 #include <sys/mman.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -63,24 +64,36 @@ struct FakeComm {
 namespace {
 ncclResult_t run(FakeComm* c, std::vector<Op>& ops) {
 	std::vector<unsigned char> host;
+	// A message larger than a mailbox travels in pieces of kBoxBytes, each with the sent / taken handshake (both sides cut it the same
+	// way).  Sends run first, so within one group a pair of ranks must not exchange multi-piece messages in BOTH directions (the
+	// product's gather does not: peers send, the root receives; the self-test's ring carries four bytes).
 	for (const Op& o : ops) { // sends first: they only need the mailbox to be free
 		if (!o.send) continue;
-		if (o.bytes > kBoxBytes) return ncclInvalidArgument;
 		Mailbox& b = c->seg->box[c->rank][o.peer];
-		if (!wait_until(b.taken, b.sent.load())) return ncclSystemError; // previous message consumed
 		if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
-		if (hipMemcpy(b.data, o.ptr, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-		b.bytes = o.bytes;
-		b.sent.fetch_add(1, std::memory_order_release);
+		size_t done = 0;
+		do {
+			const size_t piece = std::min(kBoxBytes, o.bytes - done);
+			if (!wait_until(b.taken, b.sent.load())) return ncclSystemError; // previous piece consumed
+			if (piece && hipMemcpy(b.data, static_cast<const unsigned char*>(o.ptr) + done, piece, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+			b.bytes = o.bytes; // the whole message's size: what the receiver checks
+			b.sent.fetch_add(1, std::memory_order_release);
+			done += piece;
+		} while (done < o.bytes);
 	}
 	for (const Op& o : ops) {
 		if (o.send) continue;
 		Mailbox& b = c->seg->box[o.peer][c->rank];
-		if (!wait_until(b.sent, b.taken.load() + 1)) return ncclSystemError;
-		if (b.bytes != o.bytes) { std::fprintf(stderr, "fake_rccl: rank %d expected %zu bytes from %d, got %llu\n", c->rank, o.bytes, o.peer, (unsigned long long)b.bytes); return ncclInvalidArgument; }
 		if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
-		if (hipMemcpy(o.ptr, b.data, o.bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
-		b.taken.fetch_add(1, std::memory_order_release);
+		size_t done = 0;
+		do {
+			const size_t piece = std::min(kBoxBytes, o.bytes - done);
+			if (!wait_until(b.sent, b.taken.load() + 1)) return ncclSystemError;
+			if (b.bytes != o.bytes) { std::fprintf(stderr, "fake_rccl: rank %d expected %zu bytes from %d, got %llu\n", c->rank, o.bytes, o.peer, (unsigned long long)b.bytes); return ncclInvalidArgument; }
+			if (piece && hipMemcpy(static_cast<unsigned char*>(o.ptr) + done, b.data, piece, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+			b.taken.fetch_add(1, std::memory_order_release);
+			done += piece;
+		} while (done < o.bytes);
 	}
 	ops.clear();
 	return ncclSuccess;
