@@ -207,6 +207,8 @@ def main():
     else:
         per_launch = min(max(args.steps, 1), 256)
     item_flag = bm.BM_FLAG_SAMPLE_ITEMS if multi else 0  # (chunk, sample) work items keep 1/N-of-the-pixels shards fed
+    if not by_rows and bm.frame_plan(bm.FrameParams(W, H, spp=spp_rank, max_bounces=max_bounces, flags=item_flag))["ordered"]:
+        per_launch = 1  # (BM_HELPERS=0 runs: ordered frames write pixels back with plain stores -- the frames of a launch cannot share the buffer)
 
     def params(step, flags=0):
         if by_rows:  # rank r owns the bands b with b % N == r and traces every sample of the step for them

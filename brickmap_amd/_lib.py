@@ -15,6 +15,7 @@ BM_FLAG_PRIMARY_ONLY = 1
 BM_FLAG_SAMPLE_ITEMS = 4
 BM_FLAG_COUNTERS = 2
 BM_FLAG_ORDERED = 16
+BM_FLAG_RAY_DIGEST = 32
 BRICK_INDEX_BITS = 0x00000FFF
 BRICK_LOD_BITS = 0x000FF000
 BRICK_REQUESTED_BIT = 0x20000000

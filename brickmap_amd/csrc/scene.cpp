@@ -67,7 +67,7 @@ const Tuning& tuning() {
 
 int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_in, FrameConstants* fc, bool hit_records) {
 	if (!fp_in) { set_error("null argument"); return BM_EINVAL; }
-	if (fp_in->flags & ~(BM_FLAG_PRIMARY_ONLY | BM_FLAG_COUNTERS | BM_FLAG_SAMPLE_ITEMS | BM_FLAG_ORDERED)) {
+	if (fp_in->flags & ~(BM_FLAG_PRIMARY_ONLY | BM_FLAG_COUNTERS | BM_FLAG_SAMPLE_ITEMS | BM_FLAG_ORDERED | BM_FLAG_RAY_DIGEST)) {
 		set_error("unknown frame flag (bit 8 was the retired K-slot schedule's)");
 		return BM_EINVAL;
 	}
@@ -77,7 +77,8 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_
 	// (trace.hip HELP) and, when a pixel has several samples, with (4x4 chunk, sample) work items: shorter items, a shorter tail,
 	// coherent neighbouring samples (1080p at 4 spp 4.0 -> 3.4 ms, config 3 -4 %).  BM_HELPERS=0 / 1 overrides helper lanes (A/B runs).
 	bm_frame_params promoted = *fp_in;
-	const bool ordered = (promoted.flags & (BM_FLAG_ORDERED | BM_FLAG_PRIMARY_ONLY)) != 0 || hit_records || promoted.spp < 1; // (spp = 0: nothing to trace)
+	// (hit records are chains in path order -- an ordered frame -- unless the caller asked for the order-independent ray digest)
+	const bool ordered = (promoted.flags & (BM_FLAG_ORDERED | BM_FLAG_PRIMARY_ONLY)) != 0 || (hit_records && !(promoted.flags & BM_FLAG_RAY_DIGEST)) || promoted.spp < 1; // (spp = 0: nothing to trace)
 	const bm_frame_params* const fp = &promoted;
 	if (!cam || !fp || !fc) { set_error("null argument"); return BM_EINVAL; }
 	if (fp->width <= 0 || fp->height <= 0 || fp->spp < 0 || fp->max_bounces < 0 || fp->band_rows <= 0 || fp->shard_count <= 0 ||
@@ -88,6 +89,10 @@ int Scene::fill_frame_constants(const bm_camera* cam, const bm_frame_params* fp_
 	// the kernels pack a pixel as x | y << 16 and index the shard's packed buffers with 32-bit pixel numbers
 	if (fp->width > 65535 || fp->height > 65535 || static_cast<long long>(bm_local_rows(fp)) * fp->width >= (1ll << 32)) {
 		set_error("frame too large: width and height are limited to 65535 and a shard to 2^32 pixels");
+		return BM_EINVAL;
+	}
+	if ((fp->flags & BM_FLAG_RAY_DIGEST) && (fp->max_bounces >= 255 || static_cast<long long>(fp->spp) * (fp->max_bounces + 1) >= 65536)) {
+		set_error("BM_FLAG_RAY_DIGEST: the digest counts a pixel's rays in 16 bits and keys them with 8 bits of segment: spp x segments < 65536, max_bounces < 255");
 		return BM_EINVAL;
 	}
 	const int geo_tiles_x = (fp->width + 15) / 16, geo_tiles_y = (bm_local_rows(fp) + 15) / 16;

@@ -192,6 +192,13 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	Tally tally;
 	HitInfo info;
 	uint32_t d0 = 0, d1 = 0, d2 = 0xFFFFFFFFu, d3 = 0, hseg = 2166136261u, hsh = 2166136261u, next = 0, nsh = 0, loads0 = 0;
+	// BM_FLAG_RAY_DIGEST (instrumented frames only): the hit records of a frame whose rays are traced by whichever lane is free -- helper
+	// lanes, (chunk, sample) items -- cannot be chains in path order; they are SUMS (mod 2^32) over the pixel's rays of keyed per-ray
+	// hashes, added with atomics by the lane that traced the ray (oracle.c render_pixel has the same sums):
+	//   word 4 += E(key, hit, distance bits, normal | level, brick, voxel) per extend ray, word 5 += S(key, occluded, brick, voxel | level)
+	//   per shadow ray, word 6 += ray counts, word 7 += cells visited; key = sample << 8 | segment of the path the ray belongs to
+	const bool ray_digest = DBG && (fg.flags & 32u) != 0u;
+	uint32_t ray_key = 0, ray_loads0 = 0; // of the ray in flight
 
 	RayState r;
 	r.hit = false;
@@ -399,6 +406,15 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 							hsh = hmix(hsh, static_cast<uint32_t>(info.brick_id));
 							hsh = hmix(hsh, static_cast<uint32_t>(info.sub_id) | (static_cast<uint32_t>(info.level) << 12));
 						}
+						if (ray_digest && dbg) { // (a helper's local_pixel is the owner's: the record is the path's pixel's)
+							uint32_t e = hmix(hmix(2166136261u, ray_key), static_cast<uint32_t>(occluded));
+							if (occluded) {
+								e = hmix(e, static_cast<uint32_t>(info.brick_id));
+								e = hmix(e, static_cast<uint32_t>(info.sub_id) | (static_cast<uint32_t>(info.level) << 12));
+							}
+							uint32_t* d = dbg + static_cast<size_t>(local_pixel) * 8;
+							record_atomic_add(d + 5, e); record_atomic_add(d + 6, 1u << 16); record_atomic_add(d + 7, tally.index_loads - ray_loads0);
+						}
 					}
 					if (HELP && pstate == P_HELPER) {
 						// a helper's shadow ray: the sun light goes to the OWNER's pixel (kernel.cu:341-343: atomicAdd), the lane is free again
@@ -443,6 +459,21 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 							hseg = hmix(hseg, pack_normal(pn) | (static_cast<uint32_t>(info.level) << 12));
 							hseg = hmix(hseg, static_cast<uint32_t>(info.brick_id));
 							hseg = hmix(hseg, static_cast<uint32_t>(info.sub_id));
+						}
+						if (ray_digest && dbg) {
+							uint32_t e = hmix(hmix(2166136261u, ray_key), static_cast<uint32_t>(is_hit));
+							if (is_hit) {
+								e = hmix(e, __float_as_uint(r.distance));
+								e = hmix(e, pack_normal(pn) | (static_cast<uint32_t>(info.level) << 12));
+								e = hmix(e, static_cast<uint32_t>(info.brick_id));
+								e = hmix(e, static_cast<uint32_t>(info.sub_id));
+							}
+							uint32_t* d = dbg + static_cast<size_t>(local_pixel) * 8;
+							record_atomic_add(d + 4, e); record_atomic_add(d + 6, 1u); record_atomic_add(d + 7, tally.index_loads - ray_loads0);
+							if (ray_key == 0u) { // the first extend ray of the launch's first sample: the first-hit record, written by the one lane that traced it
+								u32_in_global_memory* g = (u32_in_global_memory*)d;
+								g[0] = d0; g[1] = d1; g[2] = d2; g[3] = d3;
+							}
 						}
 					}
 					const bool primary_only = fg.flags & 1u; // BM_FLAG_PRIMARY_ONLY
@@ -518,6 +549,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						staging_word(lds_brick, k, 3) = rd.x; staging_word(lds_brick, k, 4) = rd.y; staging_word(lds_brick, k, 5) = rd.z;
 						staging_word(lds_brick, k, 6) = scolor.x; staging_word(lds_brick, k, 7) = scolor.y; staging_word(lds_brick, k, 8) = scolor.z;
 						staging_word(lds_brick, k, 9) = __uint_as_float(local_pixel);
+						if (DBG) staging_word(lds_brick, k, 10) = __uint_as_float((static_cast<uint32_t>(s) << 8) | static_cast<uint32_t>(bounces)); // the shadow ray's digest key
 						// the owner is done with this shadow ray: what connect would have done next happens now
 						if (terminated) { s++; pstate = P_GEN; need_setup = false; }
 						else { bounces++; ro = hitp; rd = bdir; r.n = pn; shadow = false; }
@@ -531,6 +563,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						rd = mk(staging_word(lds_brick, k, 3), staging_word(lds_brick, k, 4), staging_word(lds_brick, k, 5));
 						scolor = mk(staging_word(lds_brick, k, 6), staging_word(lds_brick, k, 7), staging_word(lds_brick, k, 8));
 						local_pixel = __float_as_uint(staging_word(lds_brick, k, 9));
+						if (DBG) ray_key = __float_as_uint(staging_word(lds_brick, k, 10));
 						shadow = true;
 						pstate = P_HELPER;
 						need_setup = true;
@@ -550,7 +583,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						} else {
 							pixel_store(accum + local_pixel, acc);
 						}
-						if (DBG && dbg) {
+						if (DBG && dbg && !ray_digest) { // (ray-digest records were added ray by ray)
 							u32_in_global_memory* d = (u32_in_global_memory*)(dbg + static_cast<size_t>(local_pixel) * 8);
 							if (sample_items) {
 								// one item = one sample: the pixel's record becomes an order-independent digest -- the SUMS (mod 2^32) of
@@ -585,6 +618,13 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			BM_REGION("C.set-up");
 			if (need_setup) {
 				if (shadow) r.n = mk(0.f, 0.f, 0.f); // connect passes a zeroed normal (kernel.cu:338)
+				if (DBG) {
+					// digest key of the ray about to start: its path's sample and segment.  An extend ray is segment `bounces` (already counted up
+					// for a bounce ray), a shadow ray belongs to the segment that drew it (`bounces` is counted up after connect -- or was, by the
+					// owner, when it gave the ray away: a helper got the key with the ray)
+					if (!(HELP && pstate == P_HELPER)) ray_key = (static_cast<uint32_t>(s) << 8) | static_cast<uint32_t>(bounces);
+					ray_loads0 = tally.index_loads;
+				}
 				pstate = shadow ? ((HELP && pstate == P_HELPER) ? P_HELPER : P_SHD_DONE) : P_EXT_DONE;
 				const int st = ray_setup<DBG>(sc, ro, rd, r, tally);
 				state = (st == ST_NEED && shadow) ? ST_CONN : st;

@@ -56,7 +56,15 @@ extern "C" {
                                    connect does (kernel.cu:341-343), and radiance is equal up to summation order (~1e-7 relative); and a
                                    frame with several samples per pixel is scheduled as (4x4 chunk, sample) work items, as if
                                    BM_FLAG_SAMPLE_ITEMS were set (1080p at 4 spp: 3.4 ms against 4.0).
-                                   Frames that write hit records (debug_dev != NULL) and primary-only frames are always ordered. */
+                                   Frames that write hit records (debug_dev != NULL, without BM_FLAG_RAY_DIGEST) and primary-only frames are always ordered. */
+
+#define BM_FLAG_RAY_DIGEST 32u  /* with debug_dev: the frame keeps its production plan (helper lanes, (chunk, sample) items -- NOT forced ordered) and
+                                   debug_dev holds an order-independent digest per pixel instead of hash chains in path order: words 4 / 5 are the
+                                   SUMS (mod 2^32) over the pixel's extend / shadow rays of keyed per-ray hashes -- key = sample << 8 | segment of
+                                   the ray's path; extend: hit, distance bits, normal | level, brick id, voxel id; shadow: occluded, occluder --
+                                   word 6 the ray counts, word 7 the cells visited, words 0-3 the first-hit record of the launch's first sample;
+                                   each added by the lane that traced the ray (zero the buffer first).  What pins the TIMED instantiation's hits
+                                   to the oracle bit for bit (oracle.c render_pixel holds the same sums).  spp * segments < 65536 per launch. */
 
 typedef struct bm_scene bm_scene; /* Scene + its GPUScene view (Scene.h:7-44), one GPU */
 

@@ -95,6 +95,7 @@ def lib():
             "orc_sky_probe": (None, [f, f, vp, vp, vp, vp, vp]),
             "orc_cone_sample": (None, [f, f, u, vp, vp]),
             "orc_camera_direction": (None, [C.c_double, C.c_double, vp]),
+            "orc_set_ray_digest_buffer": (None, [vp]),
             "orc_render": (C.c_double, [vp, C.POINTER(Camera), C.POINTER(Frame), vp, vp, C.POINTER(Counters), i]),
             "orc_wavefront_create": (vp, [u, i]),
             "orc_wavefront_destroy": (None, [vp]),
@@ -152,8 +153,10 @@ def camera_direction(h, v):
 
 
 def make_frame(width, height, spp=1, max_bounces=3, sample_base=0, base_frame=1, primary_only=0,
-               band_rows=0, shard_rank=0, shard_count=1, sun=(0.05, 0.1)):
-    return Frame(width, height, spp, sample_base, max_bounces, base_frame, primary_only,
+               band_rows=0, shard_rank=0, shard_count=1, sun=(0.05, 0.1), ray_digest=False):
+    """ray_digest: words 4-7 of the hit records are the order-independent per-RAY sums of the product's BM_FLAG_RAY_DIGEST frames
+    (oracle.c render_pixel) instead of hash chains in path order."""
+    return Frame(width, height, spp, sample_base, max_bounces, base_frame, (1 if primary_only else 0) | (2 if ray_digest else 0),
                  band_rows if band_rows > 0 else height, shard_rank, shard_count, sun[0], sun[1])
 
 
@@ -244,14 +247,26 @@ class World:
                     brick_id=int(out4[2]), sub_id=int(out4[3]), index_loads=int(loads.value))
 
     def render(self, cam, frame, accum=None, want_dbg=True, threads=1):
-        """Canonical per-pixel render (mode B). Returns (accum[H,W,4], dbg[H,W,8] | None, counters dict, seconds)."""
+        """Canonical per-pixel render (mode B). Returns (accum[H,W,4], dbg[H,W,8] | None, counters dict, seconds).
+        With want_dbg the same pass also fills self.last_ray_digest: the hit records with words 4 / 5 replaced by the order-independent
+        per-RAY sums (what the product's BM_FLAG_RAY_DIGEST frames hold; oracle.c render_pixel)."""
         W, H = frame.width, frame.height
         if accum is None:
             accum = np.zeros((H, W, 4), np.float32)
         dbg = np.zeros((H, W, 8), np.uint32) if want_dbg else None
+        sums = np.zeros((H, W, 2), np.uint32) if want_dbg else None
         cnt = Counters()
-        secs = self.L.orc_render(self.h, C.byref(cam), C.byref(frame), _ptr(accum),
-                                 _ptr(dbg) if dbg is not None else None, C.byref(cnt), threads)
+        self.L.orc_set_ray_digest_buffer(_ptr(sums) if sums is not None else None)
+        try:
+            secs = self.L.orc_render(self.h, C.byref(cam), C.byref(frame), _ptr(accum),
+                                     _ptr(dbg) if dbg is not None else None, C.byref(cnt), threads)
+        finally:
+            self.L.orc_set_ray_digest_buffer(None)
+        self.last_ray_digest = None
+        if dbg is not None:
+            self.last_ray_digest = dbg.copy()
+            if not (frame.primary_only & 2):
+                self.last_ray_digest[..., 4:6] = sums
         return accum, dbg, cnt.as_dict(), secs
 
 

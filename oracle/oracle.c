@@ -916,7 +916,8 @@ typedef struct {
 	int sample_base;   /* absolute index of the first sample (progressive accumulation)    */
 	int max_bounces;   /* kernel.cu:13 MAX_BOUNCES (3 => up to 4 segments per path)         */
 	unsigned base_frame; /* kernel.cu:369 `frame`, starts at 1                              */
-	int primary_only;  /* config 1: extend the primary ray only, no shadow ray, no bounce    */
+	int primary_only;  /* bit 0: config 1 -- extend the primary ray only, no shadow ray, no bounce;
+	                      bit 1: dbg holds the order-independent RAY DIGEST (render_pixel)      */
 	int band_rows, shard_rank, shard_count; /* interleaved row bands; (height,0,1) = whole image */
 	float sun_x, sun_y; /* variables.cpp:3 default (0.05, 0.1)                             */
 } orc_frame;
@@ -989,6 +990,13 @@ static inline uint32_t pack_normal(v3 n) {
  *  [0] primary distance bits  [1] packed normal | hit<<8 | level<<12  [2] brick id  [3] sub id
  *  [4] hash over all extend segments  [5] hash over all shadow rays  [6] extend rays | shadow rays<<16
  *  [7] index loads (outer DDA iterations) of this pixel's rays
+ * With primary_only bit 1 (the product's BM_FLAG_RAY_DIGEST: frames whose rays are traced by whichever lane is free, in any order)
+ * words 4-7 are SUMS (mod 2^32) over the pixel's rays instead of chains over them:
+ *  [4] sum over its extend rays of  E = hmix(... hmix(2166136261, key), is_hit) [, distance bits, normal | level<<12, brick id, sub id]
+ *  [5] sum over its shadow rays of  S = hmix(hmix(2166136261, key), occluded) [, brick id, sub id | level<<12]
+ *      key = sample << 8 | segment: sample counted from 0 inside the call, segment = number of the path's extend ray (the one that
+ *      produced the shadow ray, for S) -- the keyed hash makes "the same rays" mean "the same ray at the same place of the same path"
+ *  [6] extend rays | shadow rays<<16   [7] index loads, both as before (sums anyway)
  */
 typedef struct {
 	orc_world* w;
@@ -1001,6 +1009,11 @@ typedef struct {
 	int atomic_requests;
 	char pad[128]; /* one job per thread in an array: keep the per-thread counters of neighbours off each other's cache lines */
 } __attribute__((aligned(128))) render_job;
+
+/* Optional second output of orc_render (test infrastructure): per pixel of the full frame the two ray-digest sums (words 4 and 5 of a
+ * primary_only-bit-1 record), so that ONE render yields both the hash chains and the sums.  NULL = off. */
+static uint32_t* orc_ray_digest_out = NULL;
+ORC_API void orc_set_ray_digest_buffer(uint32_t* two_words_per_pixel) { orc_ray_digest_out = two_words_per_pixel; }
 
 static int row_in_shard(const orc_frame* f, int y) {
 	int band = f->band_rows > 0 ? f->band_rows : f->height;
@@ -1017,7 +1030,10 @@ static void render_pixel(render_job* job, const cam_basis* cb, const orc_sky_sta
 	float r = acc[0], g = acc[1], b = acc[2], a = acc[3];
 	uint32_t d0 = 0, d1 = 0, d2 = 0xFFFFFFFFu, d3 = 0, hseg = 2166136261u, hsh = 2166136261u, next = 0, nsh = 0;
 	uint64_t loads_before = job->cnt.index_loads;
+	const int ray_digest = (f->primary_only & 2) != 0, primary_only = (f->primary_only & 1) != 0;
+	uint32_t sum_e = 0, sum_s = 0;
 	for (int s = 0; s < f->spp; s++) {
+		int seg = -1; /* number of the path's current extend ray */
 		const unsigned slot = p + (unsigned)(f->sample_base + s) * W * H;
 		primary_ray pr;
 		make_primary(cb, job->cam, f->base_frame, slot, 0u, W, H, &pr);
@@ -1046,7 +1062,18 @@ static void render_pixel(render_job* job, const cam_basis* cb, const orc_sky_sta
 				hseg = hmix(hseg, (uint32_t)hit.brick_id);
 				hseg = hmix(hseg, (uint32_t)hit.sub_id);
 			}
-			if (f->primary_only) {
+			seg++;
+			{
+				uint32_t e = hmix(hmix(2166136261u, ((uint32_t)s << 8) | (uint32_t)seg), (uint32_t)is_hit);
+				if (is_hit) {
+					e = hmix(e, fbits(distance));
+					e = hmix(e, pack_normal(normal) | ((uint32_t)hit.level << 12));
+					e = hmix(e, (uint32_t)hit.brick_id);
+					e = hmix(e, (uint32_t)hit.sub_id);
+				}
+				sum_e += e;
+			}
+			if (primary_only) {
 				if (!is_hit) { v3 c = mul3(throughput, sky_sunsky(sky, direction)); r += c.x; g += c.y; b += c.z; }
 				a += 1.f;
 				break;
@@ -1090,6 +1117,11 @@ static void render_pixel(render_job* job, const cam_basis* cb, const orc_sky_sta
 					nsh++;
 					hsh = hmix(hsh, (uint32_t)occluded);
 					if (occluded) { hsh = hmix(hsh, (uint32_t)sh.brick_id); hsh = hmix(hsh, (uint32_t)sh.sub_id | ((uint32_t)sh.level << 12)); }
+					{
+						uint32_t e = hmix(hmix(2166136261u, ((uint32_t)s << 8) | (uint32_t)seg), (uint32_t)occluded);
+						if (occluded) { e = hmix(e, (uint32_t)sh.brick_id); e = hmix(e, (uint32_t)sh.sub_id | ((uint32_t)sh.level << 12)); }
+						sum_s += e;
+					}
 					if (!occluded) { r += scolor.x; g += scolor.y; b += scolor.z; }
 				}
 				if (terminated) break;
@@ -1101,9 +1133,10 @@ static void render_pixel(render_job* job, const cam_basis* cb, const orc_sky_sta
 		}
 	}
 	acc[0] = r; acc[1] = g; acc[2] = b; acc[3] = a;
+	if (orc_ray_digest_out) { orc_ray_digest_out[(size_t)p * 2] = sum_e; orc_ray_digest_out[(size_t)p * 2 + 1] = sum_s; }
 	if (job->dbg) {
 		uint32_t* d = job->dbg + (size_t)p * 8;
-		d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = hseg; d[5] = hsh; d[6] = next | (nsh << 16);
+		d[0] = d0; d[1] = d1; d[2] = d2; d[3] = d3; d[4] = ray_digest ? sum_e : hseg; d[5] = ray_digest ? sum_s : hsh; d[6] = next | (nsh << 16);
 		d[7] = (uint32_t)(job->cnt.index_loads - loads_before);
 	}
 }

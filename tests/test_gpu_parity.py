@@ -39,6 +39,10 @@ def gpu_render(bm, torch, scene, cam, params, accum=None, want_dbg=True, also_pl
           the kernel bench.py times): identical terminated-path counts, radiance equal up to summation order (2e-5);
       (c) where the caller checks traversal counters (BM_FLAG_COUNTERS on a resident scene with clean counters): with helper lanes AND
           counters, instrumented, no hit records -- the counters must equal the ordered frame's, i.e. the helpers walked the same rays;
+      (d) as a production frame WITH hit records of its own (BM_FLAG_RAY_DIGEST: trace_paths<true, *, true>, helper lanes, (chunk,
+          sample) items where the library would choose them): same accumulator as (b) up to summation order, and an order-independent
+          per-pixel digest of every ray's hit -- kept in gpu_render.last_digest for the caller to compare with the oracle's
+          (assert_ray_digest): the instantiation family bench.py times, compared with the oracle on HITS, bit for bit.
     So every case that checks the instrumented kernel against the oracle also pins the benchmarked one."""
     import copy
     rows = bm.local_rows(params)
@@ -92,7 +96,39 @@ def gpu_render(bm, torch, scene, cam, params, accum=None, want_dbg=True, also_pl
         assert scene.counters() == helper_counts, "helper lanes: traversal counters differ from the ordered frame's"
         assert np.array_equal(helper_acc[..., 3], a[..., 3])
         np.testing.assert_allclose(helper_acc[..., :3], a[..., :3], rtol=2e-5, atol=1e-7, err_msg="helper lanes (instrumented): radiance differs")
+    gpu_render.last_digest = None
+    if want_dbg and not (params.flags & (bm.BM_FLAG_ORDERED | bm.BM_FLAG_PRIMARY_ONLY)):
+        info = scene.info()
+        if info["resident_bricks"] == info["total_bricks"]:  # (an extra frame of a streaming scene changes what is requested)
+            dp = copy.copy(params)
+            dp.flags = (params.flags & ~bm.BM_FLAG_COUNTERS) | bm.BM_FLAG_RAY_DIGEST
+            acc_d = before.clone() if before is not None else torch.zeros_like(accum)
+            dig = torch.zeros((rows, params.width, 8), dtype=torch.int32, device="cuda:0")
+            scene.render(cam, dp, acc_d, debug=dig)
+            torch.cuda.synchronize()
+            if before is not None:
+                g = acc_d.cpu().numpy()
+                assert np.array_equal(g[..., 3], a[..., 3]), "ray-digest frame: terminated-path counts differ"
+                np.testing.assert_allclose(g[..., :3], a[..., :3], rtol=2e-5, atol=1e-7, err_msg="ray-digest frame: radiance differs")
+            gpu_render.last_digest = dig.cpu().numpy().view(np.uint32)
+            # ray counts and cells visited are sums either way: they must equal the ordered frame's records
+            d_ord = dbg.cpu().numpy().view(np.uint32)
+            assert np.array_equal(gpu_render.last_digest[..., 6:], d_ord[..., 6:]) and np.array_equal(gpu_render.last_digest[..., :4], d_ord[..., :4])
     return a, (dbg.cpu().numpy().view(np.uint32) if want_dbg else None)
+
+
+gpu_render.last_digest = None
+
+
+def assert_ray_digest(world, rows=None):
+    """The production-plan frame of the last gpu_render call (helper lanes, float atomics: the timed instantiation family) traced the
+    oracle's rays: per pixel the keyed sums over all its extend / shadow rays of (hit, distance bits, normal, level, brick id, voxel
+    id) / (occluded, occluder), the ray counts and the cells visited equal those of the oracle's last render, bit for bit."""
+    got, want = gpu_render.last_digest, world.last_ray_digest
+    assert got is not None and want is not None
+    if rows is not None:
+        got, want = got[rows], want[rows]
+    assert np.array_equal(got, want), f"{np.count_nonzero((got != want).any(-1))} pixels whose ray digest differs from the oracle's"
 
 
 def cameras(bm, orc, grid, pos=None, h=0.8, v=-0.5, direction=None):
@@ -210,6 +246,7 @@ def test_paths_match_oracle(case, bm, orc, torch_cuda, scene256, world256):
     acc, dbg = gpu_render(bm, torch_cuda, scene256, cam, p)
     oacc, odbg, ocnt, _ = world256.render(ocam, orc.make_frame(W, H, spp=spp, max_bounces=mb))
     assert np.array_equal(dbg, odbg), f"{np.count_nonzero((dbg != odbg).any(-1))} pixels with different hit records"
+    assert_ray_digest(world256)  # ... and the helper-lane frame's hits, ray by ray
     assert_radiance(acc, oacc)
     assert scene256.counters() == ocnt
     assert np.all(acc[..., 3] == spp)  # every path terminates exactly once
@@ -223,6 +260,7 @@ def test_lens_and_focal_distance(bm, orc, torch_cuda, scene256, world256):
     acc, dbg = gpu_render(bm, torch_cuda, scene256, cam, p)
     oacc, odbg, _, _ = world256.render(ocam, orc.make_frame(64, 48, spp=2, max_bounces=3))
     assert np.array_equal(dbg, odbg)
+    assert_ray_digest(world256)
     assert_radiance(acc, oacc)
 
 
@@ -233,6 +271,7 @@ def test_sun_position_change(bm, orc, torch_cuda, scene256, world256):
     acc, dbg = gpu_render(bm, torch_cuda, scene256, cam, p)
     oacc, odbg, _, _ = world256.render(ocam, orc.make_frame(64, 48, spp=1, max_bounces=3, sun=sun))
     assert np.array_equal(dbg, odbg)
+    assert_ray_digest(world256)
     assert_radiance(acc, oacc)
 
 
@@ -252,6 +291,7 @@ def test_lod_levels(bm, orc, torch_cuda):
     levels = set(((odbg[..., 1] >> 12) & 0xF)[odbg[..., 1] != 0].tolist())
     assert {0, 1, 2} <= levels, f"test frame does not exercise all LoD levels: {levels}"
     assert np.array_equal(dbg, odbg)
+    assert_ray_digest(w)
     assert_radiance(acc, oacc)
     assert scene.counters() == ocnt and ocnt["byte_tests"] > 0
     scene.close()
@@ -514,6 +554,7 @@ def test_full_size_config2_properties(bm, orc, torch_cuda):
     p = bm.FrameParams(W, H, spp=1, max_bounces=3, flags=bm.BM_FLAG_COUNTERS)
     scene.counters_reset()
     acc, dbg = gpu_render(bm, torch, scene, cam, p)
+    digest_full = gpu_render.last_digest
     cnt = scene.counters()
     assert np.all(acc[..., 3] == 1.0) and np.all(np.isfinite(acc))
     assert cnt["paths"] == W * H and cnt["paths"] <= cnt["extend_rays"] <= 4 * cnt["paths"] and cnt["shadow_rays"] <= cnt["extend_rays"]
@@ -533,6 +574,10 @@ def test_full_size_config2_properties(bm, orc, torch_cuda):
     rows = bm.dist.shard_rows(H, 1, 7, 60)
     assert np.array_equal(dbg[rows], odbg[rows])
     assert_radiance(acc[rows], oacc[rows])
+    # the frame bench.py times -- trace_paths<*, false, true> on the full-size frame -- against the oracle on hits: the digest of the
+    # production-plan render (the first gpu_render call above) on the same 18 rows
+    assert np.array_equal(digest_full[rows], w.last_ray_digest[rows]), "config 2 at full size: the helper-lane frame's ray digest differs from the oracle's"
+    assert int((digest_full[..., 6] & 0xFFFF).sum()) == cnt["extend_rays"] and int(digest_full[..., 7].astype(np.uint64).sum()) == cnt["index_loads"]
     scene.close()
 
 
@@ -619,6 +664,7 @@ def test_randomised_views_match_oracle(bm, orc, torch_cuda, scene256, world256):
         acc, dbg = gpu_render(bm, torch_cuda, scene256, cam, p)
         oacc, odbg, _, _ = world256.render(ocam, orc.make_frame(W, H, spp=spp, max_bounces=mb, sample_base=sb, sun=sun))
         assert np.array_equal(dbg, odbg), f"trial {trial}: pos={pos} h={h} v={v}"
+        assert_ray_digest(world256)
         finite = np.isfinite(oacc)
         assert np.array_equal(np.isfinite(acc), finite), f"trial {trial}"
         assert_radiance(np.where(finite, acc, 0), np.where(finite, oacc, 0))

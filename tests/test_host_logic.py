@@ -153,13 +153,41 @@ def test_bench_helpers_run_without_a_gpu():
     assert 1 <= physical <= logical and 1 <= b.cpu_quota() <= logical and isinstance(model, str)
     for wl in ("config2", "config3", "config5"):
         t = b.pmc_traffic(wl)
-        assert t["traffic"] and t["traffic"] > 0 and f"{b.PROFILE_ROUNDS[0]}_pmc_summary_{wl}.json" in t["traffic_source"]
-        lim = b.limiter_of(wl)
-        assert lim["limiter"] and f"_pmc_summary_{wl}.json" in lim["limiter_source"]
+        assert t["traffic_per_step"] and t["traffic_per_step"] > 0 and f"_pmc_summary_{wl}.json" in t["traffic_source"]
+        lim = b.limiter_of(wl, 7)
+        assert lim["limiter"] and "7 waves per SIMD" in lim["limiter"] and f"_pmc_summary_{wl}.json" in lim["limiter_source"]
     assert b.limiter_of("config1") == {"limiter": None, "limiter_source": None}  # no committed PMC summary: no claim
-    assert b.pmc_traffic("no-such-workload") == {"traffic": None, "valu_lanes": None, "valu_insts": None, "traffic_source": None}
-    f = b.counter_figures("config2", 1.0e-3)
-    assert 0 < f["frac_by_counters"] < 1 and 10 < f["valu_lanes"] < 64 and f["valu_insts"] > 1e8
+    assert b.pmc_traffic("no-such-workload") == {"traffic_per_step": None, "valu_lanes": None, "valu_insts": None, "traffic_source": None}
+    f = b.counter_figures("config2", 1.0e-3, 20)
+    assert 0 < f["frac_by_counters"] < 1 and 10 < f["valu_lanes"] < 64 and f["valu_insts"] > 1e8 and f["traffic"] == 20 * f["traffic_per_step"]
+    assert set(f["traffic_age"]) == {"summary", "collected_at_commit", "head", "commits_behind_head"} and f["traffic_age"]["summary"] in f["traffic_source"]
+    # steps are cut into launches as evenly as possible (bench.py issue / the frame ring)
+    assert b.batches(3, 20, 20) == [(3, 20)] and b.batches(0, 7, 5) == [(0, 4), (4, 3)] and b.batches(0, 0, 5) == [] and b.batches(0, 300, 256) == [(0, 150), (150, 150)]
+
+
+def test_frame_plan_and_ticket_limits():
+    """bm_frame_plan_of (host only): what the library decides for a frame.  ADVICE r05: (chunk, sample) items are the library's own choice
+    only where their tickets fit the 32-bit hand-out -- a default-flag frame at very high spp falls back to pixel items (which carry no
+    spp factor) instead of being refused; a caller who ASKS for sample items that do not fit is refused; unknown flags are refused."""
+    import brickmap_amd as bm
+    p1 = bm.frame_plan(bm.FrameParams(1920, 1080, spp=1, max_bounces=3))
+    assert (p1["helpers"], p1["sample_items"], p1["ordered"], p1["xcd_handout"], p1["refill_min"], p1["instrumented"]) == (1, 0, 0, 0, 24, 0)
+    p4 = bm.frame_plan(bm.FrameParams(1920, 1080, spp=4, max_bounces=3))
+    assert p4["sample_items"] == 1 and p4["flags"] & bm.BM_FLAG_SAMPLE_ITEMS
+    for W, H, spp in ((1920, 1080, 5000), (3840, 2160, 1000), (7680, 4320, 300)):  # (beyond the limits the advisor computed: 4100 / 950 / 250)
+        hi = bm.frame_plan(bm.FrameParams(W, H, spp=spp, max_bounces=3))
+        assert hi["sample_items"] == 0 and hi["helpers"] == 1 and not hi["flags"] & bm.BM_FLAG_SAMPLE_ITEMS
+        with pytest.raises(bm.BrickmapError, match="ticket"):
+            bm.frame_plan(bm.FrameParams(W, H, spp=spp, max_bounces=3, flags=bm.BM_FLAG_SAMPLE_ITEMS))
+    assert bm.frame_plan(bm.FrameParams(3840, 2160, spp=4, max_bounces=7), hit_records=True)["ordered"] == 1  # hit records: chains in path order
+    d = bm.frame_plan(bm.FrameParams(3840, 2160, spp=4, max_bounces=7, flags=bm.BM_FLAG_RAY_DIGEST), hit_records=True)
+    assert (d["ordered"], d["helpers"], d["sample_items"], d["xcd_handout"], d["instrumented"]) == (0, 1, 1, 1, 1)  # ... unless the ray digest is asked for
+    assert bm.frame_plan(bm.FrameParams(64, 64, spp=2, flags=bm.BM_FLAG_ORDERED))["ordered"] == 1
+    with pytest.raises(bm.BrickmapError, match="unknown frame flag"):
+        bm.frame_plan(bm.FrameParams(64, 64, flags=8))  # the retired K-slot schedule's bit
+    with pytest.raises(bm.BrickmapError, match="RAY_DIGEST"):
+        bm.frame_plan(bm.FrameParams(64, 64, spp=20000, max_bounces=3, flags=bm.BM_FLAG_RAY_DIGEST))
+    assert bm.tuning_overrides() == {}
 
 
 def test_retired_experiments_stay_out_of_the_kernel_sources():
