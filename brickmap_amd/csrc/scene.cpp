@@ -240,7 +240,7 @@ int Scene::init(int grid_size, int grid_height) {
 		return BM_EINVAL;
 	}
 	if (world.dims.cells > 1024 || world.dims.cells_height > 1024) { // candidates take 24-bit products of brick coordinates and of their distance to the camera (traverse.h)
-		set_error("worlds larger than 8192 voxels a side are not supported");
+		set_error("world too large: at most 8192 voxels along an axis (and see the cube-field limit: cubic worlds up to 5760 voxels a side)");
 		return BM_EINVAL;
 	}
 	// the walk keeps a ray's cell as ONE 32-bit byte offset into the 8 planes of the octant cube field, whose rows are padded to a
@@ -250,7 +250,7 @@ int Scene::init(int grid_size, int grid_height) {
 		while ((1 << shift) < world.dims.cells + 2) ++shift;
 		const uint64_t plane = (static_cast<uint64_t>(world.dims.cells + 2) << shift) * static_cast<uint64_t>(world.dims.cells_height + 2);
 		if (plane * 8 >= (1ull << 32)) {
-			set_error("world too large: the octant cube field (8 planes, rows padded to a power of two) must stay below 4 GiB");
+			set_error("world too large: the octant cube field (8 planes of (cells_h + 2) x (cells + 2) rows padded to a power of two) must stay below 4 GiB -- cubic worlds up to 5760 voxels a side");
 			return BM_EINVAL;
 		}
 	}
@@ -584,6 +584,7 @@ int Scene::allocate_device() {
 		const uint64_t pxy = static_cast<uint64_t>(X) << shift, plane = pxy * static_cast<uint64_t>(Z);
 		if (pxy >= (1ull << 23) || plane * 8 >= (1ull << 32)) { set_error("world too large for the 32-bit cube-field offsets of the walk"); return BM_EINVAL; }
 		BM_HIP(hipMalloc(reinterpret_cast<void**>(&d_cube_field_), plane * 8));
+		BM_HIP(hipMemset(d_cube_field_, 255, plane * 8)); // the row padding reads as border cells: a stray offset ends a walk instead of reading whatever was there
 		// 8 planes x Z slices, each X rows of X bytes -> rows of 2^shift bytes (the padding is never read)
 		for (int o = 0; o < 8; ++o)
 			BM_HIP(hipMemcpy2D(d_cube_field_ + static_cast<size_t>(o) * plane, static_cast<size_t>(1) << shift, field.data() + static_cast<size_t>(o) * X * X * Z, X, X,

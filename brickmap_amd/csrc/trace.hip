@@ -550,9 +550,13 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						staging_word(lds_brick, k, 6) = scolor.x; staging_word(lds_brick, k, 7) = scolor.y; staging_word(lds_brick, k, 8) = scolor.z;
 						staging_word(lds_brick, k, 9) = __uint_as_float(local_pixel);
 						if (DBG) staging_word(lds_brick, k, 10) = __uint_as_float((static_cast<uint32_t>(s) << 8) | static_cast<uint32_t>(bounces)); // the shadow ray's digest key
-						// the owner is done with this shadow ray: what connect would have done next happens now
+						// the owner is done with this shadow ray: what connect would have done next happens now.  (Invariants: the hand-over runs
+						// BEFORE the generate block of the same pass, which either starts the owner's next primary ray or idles the lane; the owner
+						// no longer has a shadow ray in flight either way -- say so; and a lane that TAKES a ray keeps pstate == P_HELPER through
+						// the set-up below and through connect, so it never reaches the shade / generate / write-back code with the owner's pixel)
+						shadow = false;
 						if (terminated) { s++; pstate = P_GEN; need_setup = false; }
-						else { bounces++; ro = hitp; rd = bdir; r.n = pn; shadow = false; }
+						else { bounces++; ro = hitp; rd = bdir; r.n = pn; }
 					}
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 					__builtin_amdgcn_wave_barrier();

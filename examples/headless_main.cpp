@@ -1,11 +1,13 @@
 // examples/headless_main.cpp -- the reference's main loop (src/main.cpp:100-147) without the window:
 // State + Scene + generate(), then per frame launch_kernels -> process_load_queue, finally a PPM of the
 // resolved frame.  Build: see `make -C examples` (g++ on this file, linked against libbrickmap_hip.so).
-//   usage: headless_main [grid_size grid_height width height frames out.ppm [wavefront]]
-// With the last argument the frames are rendered with the reference's own queue schedule (one segment per call).
+//   usage: headless_main [grid_size grid_height width height frames out.ppm [wavefront | ring]]
+// With `wavefront` the frames are rendered with the reference's own queue schedule (one segment per call); with `ring` the
+// world is made resident first and all frames are ONE launch of the persistent kernel (launch_frames, the frame ring).
 #include <cstdint>
 #include <fstream>
 #include <iostream>
+#include <string>
 #include <vector>
 
 #include "../include/brickmap.hpp"
@@ -17,7 +19,7 @@ int main(int argc, char** argv) {
 	const size_t width = argc > 3 ? std::atoi(argv[3]) : 1920, height = argc > 4 ? std::atoi(argv[4]) : 1080;
 	const int frames = argc > 5 ? std::atoi(argv[5]) : 64;
 	const char* out = argc > 6 ? argv[6] : "frame.ppm";
-	const bool wavefront = argc > 7;
+	const bool wavefront = argc > 7 && std::string(argv[7]) == "wavefront", ring = argc > 7 && std::string(argv[7]) == "ring";
 
 	State state(width, height);                 // main.cpp:102
 	Scene scene(grid_size, grid_height);        // main.cpp:104
@@ -33,6 +35,9 @@ int main(int argc, char** argv) {
 			launch_kernels(state, state.blit_buffer, scene.gpuScene, queues); // main.cpp:142
 			scene.process_load_queue();                                         // main.cpp:144 (the swap of :146 is inside)
 		}
+	} else if (ring) {
+		scene.preload_all();                                                // (bricks are serviced between launches: a ring wants them resident)
+		launch_frames(state, state.blit_buffer, scene.gpuScene, frames);   // main.cpp:117-147, `frames` iterations in one launch
 	} else {
 		for (int frame = 0; frame < frames; ++frame) {
 			launch_kernels(state, state.blit_buffer, scene.gpuScene); // main.cpp:142

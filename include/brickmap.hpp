@@ -5,6 +5,7 @@
 //   State           state.h:5-34                             (ray queues / GL interop are gone: paths live in registers)
 //   Scene           Scene.h:7-44, Scene.cpp:29-258
 //   launch_kernels  launch.h:6, kernel.cu:366-439            (fused per-pixel paths; or, with a Wavefront, the reference's queue schedule)
+//   launch_frames   main.cpp:117-147                         (that many iterations of the frame loop as ONE launch: the frame ring)
 //   hip(...)        assert_cuda.h:5, assert_cuda.cpp:3-13     (print, then exit(code): the reference's cuda() macro)
 // A maintainer swaps `#include "launch.h"` + the CUDA sources for this header and links libbrickmap_hip.so;
 // see INTEGRATION.md for the exact diff against src/main.cpp.
@@ -144,35 +145,73 @@ inline bool camera_changed(const Camera& last) {
 }
 } // namespace detail
 
-// launch_kernels (launch.h:6, kernel.cu:366-439).  The cudaSurfaceObject_t and the three queue pointers of the
-// reference signature are gone (no GL surface; paths live in registers); `spp` complete paths per pixel are
-// traced per call instead of one bounce of every in-flight path.  As in the reference the call blocks until
-// the frame is done (kernel.cu:431) and a camera / sun change resets the accumulation (kernel.cu:387-403).
-inline int launch_kernels(State& state, vec4* blit_buffer, Scene::GPUScene gpuScene, int spp = 1, int max_bounces = 3) {
-	static bool first_time = true;
-	static int sample_base = 0;
-	static Camera last;
-	bool reset_buffer = first_time || detail::camera_changed(last);
-	first_time = false;
+namespace detail {
+// the statics of launch_kernels (kernel.cu:369,387-403: frame counter, first call, last camera) shared by its two forms
+struct FusedStatics {
+	bool first_time = true;
+	int sample_base = 0;
+	Camera last;
+};
+inline FusedStatics& fused_statics() { static FusedStatics s; return s; }
+// kernel.cu:387-403: a camera / sun change (or the first call) resets the accumulation; returns the frame parameters of the next call
+inline bm_frame_params begin_frames(State& state, vec4* blit_buffer, int spp, int max_bounces) {
+	FusedStatics& st = fused_statics();
+	bool reset_buffer = st.first_time || camera_changed(st.last);
+	st.first_time = false;
 	if (sun_position_changed) {
 		sun_position_changed = false;
 		reset_buffer = true;
 	}
 	if (reset_buffer) {
 		BM_CHECKED(bm_buffer_zero(state.device, blit_buffer, state.screen_width * state.local_rows * sizeof(vec4), nullptr));
-		sample_base = 0;
+		st.sample_base = 0;
 	}
-	const bm_camera cam = detail::camera_to_c();
-	bm_frame_params fp = detail::frame_params(state, max_bounces);
+	bm_frame_params fp = frame_params(state, max_bounces);
 	fp.spp = spp;
-	fp.sample_base = sample_base;
+	fp.sample_base = st.sample_base;
 	// a shard has few pixels and (usually) many samples: (4x4 chunk, sample) work items keep the persistent waves fed
 	if (state.shard.count > 1) fp.flags |= BM_FLAG_SAMPLE_ITEMS;
+	return fp;
+}
+} // namespace detail
+
+// launch_kernels (launch.h:6, kernel.cu:366-439).  The cudaSurfaceObject_t and the three queue pointers of the
+// reference signature are gone (no GL surface; paths live in registers); `spp` complete paths per pixel are
+// traced per call instead of one bounce of every in-flight path.  As in the reference the call blocks until
+// the frame is done (kernel.cu:431) and a camera / sun change resets the accumulation (kernel.cu:387-403).
+inline int launch_kernels(State& state, vec4* blit_buffer, Scene::GPUScene gpuScene, int spp = 1, int max_bounces = 3) {
+	const bm_camera cam = detail::camera_to_c();
+	const bm_frame_params fp = detail::begin_frames(state, blit_buffer, spp, max_bounces);
 	BM_CHECKED(bm_render_frame(gpuScene.handle, &cam, &fp, reinterpret_cast<float*>(blit_buffer), nullptr, nullptr));
 	BM_CHECKED(bm_synchronize(gpuScene.handle));
-	sample_base += spp;
-	last = camera;
+	detail::fused_statics().sample_base += spp;
+	detail::fused_statics().last = camera;
 	return 0; // the reference always returns cudaSuccess (kernel.cu:438)
+}
+
+// `frames` consecutive iterations of the reference's frame loop (main.cpp:117-147: launch_kernels once per frame) for the current
+// camera and sun as ONE launch of the persistent kernel (bm_render_frames, the "frame ring"): exactly the frames that many
+// launch_kernels calls render -- each with its own sample offsets, ticket counters and rays, all accumulating into blit_buffer like
+// consecutive frames of the reference (kernel.cu:319-322,341-343) -- but a wave that has run out of work in frame i starts on
+// frame i+1 by itself, so the end of a frame is covered by the next one (1080p, 1 spp: 0.86 instead of 1.03 ms per frame).
+// Blocks until the last frame is done.  A host whose camera moves every frame keeps calling launch_kernels.
+inline int launch_frames(State& state, vec4* blit_buffer, Scene::GPUScene gpuScene, int frames, int spp = 1, int max_bounces = 3) {
+	if (frames < 1) return 0;
+	const bm_camera cam = detail::camera_to_c();
+	const bm_frame_params first = detail::begin_frames(state, blit_buffer, spp, max_bounces);
+	for (int done = 0; done < frames;) {
+		const int n = frames - done < 256 ? frames - done : 256; // (bm_render_frames takes up to 256 frames per launch)
+		std::vector<bm_camera> cams(static_cast<size_t>(n), cam);
+		std::vector<bm_frame_params> fps(static_cast<size_t>(n), first);
+		std::vector<float*> buffers(static_cast<size_t>(n), reinterpret_cast<float*>(blit_buffer));
+		for (int i = 0; i < n; ++i) fps[static_cast<size_t>(i)].sample_base = first.sample_base + (done + i) * spp;
+		BM_CHECKED(bm_render_frames(gpuScene.handle, n, cams.data(), fps.data(), buffers.data(), nullptr, nullptr));
+		done += n;
+	}
+	BM_CHECKED(bm_synchronize(gpuScene.handle));
+	detail::fused_statics().sample_base += frames * spp;
+	detail::fused_statics().last = camera;
+	return 0;
 }
 
 // ---- multi-GPU: one process (or thread) per GPU, every one with its own Scene replica, State shard and Comm.
@@ -201,6 +240,15 @@ inline void gather_frame(Comm& comm, const State& state, vec4* frame_on_root, in
 	BM_CHECKED(bm_gather_frame(comm.handle, reinterpret_cast<const float*>(state.blit_buffer), reinterpret_cast<float*>(frame_on_root),
 							   static_cast<int>(state.screen_height), static_cast<int>(state.screen_width), state.shard.count > 1 ? state.shard.band_rows : static_cast<int>(state.screen_height),
 							   root, nullptr));
+}
+
+// The exchange of a BATCH of frames (what a rank rendered with launch_frames-style launches into one allocation of `count` packed
+// shard buffers): one message per peer for the whole batch (bm_gather_frames).  packed = count x local_rows x width float4,
+// frames_on_root = count x height x width float4 (ignored on the other ranks).
+inline void gather_frames(Comm& comm, const State& state, const vec4* packed, vec4* frames_on_root, int count, int root = 0) {
+	BM_CHECKED(bm_gather_frames(comm.handle, reinterpret_cast<const float*>(packed), reinterpret_cast<float*>(frames_on_root), count,
+								static_cast<int>(state.screen_height), static_cast<int>(state.screen_width),
+								state.shard.count > 1 ? state.shard.band_rows : static_cast<int>(state.screen_height), root, nullptr));
 }
 
 // Streams that run side by side (bm_probe_streams): for a host that pipelines frames over two streams with the exchange on a third.

@@ -613,6 +613,15 @@ def test_cpp_headless_example_streams_and_renders(bm, torch_cuda, tmp_path):
     assert data.startswith(b"P6\n160 96\n255\n") and len(data) == len(b"P6\n160 96\n255\n") + 160 * 96 * 3
     px = np.frombuffer(data[len(b"P6\n160 96\n255\n"):], np.uint8)
     assert px.max() > 0 and len(np.unique(px)) > 16  # an actual image, not a constant
+    # launch_frames (the frame ring through the C++ mirror): 24 frames as ONE launch on the resident world give the image of 24
+    # launch_kernels calls (here: of the streamed run once everything it sees is resident -- same paths, 8-bit pixels)
+    ring = tmp_path / "ring.ppm"
+    r = subprocess.run([os.path.join(ROOT, "examples", "headless_main"), "256", "256", "160", "96", "24", str(ring), "ring"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rp = np.frombuffer(ring.read_bytes()[len(b"P6\n160 96\n255\n"):], np.uint8)
+    assert rp.shape == px.shape and rp.max() > 0
+    # the streamed run's first frames treated unloaded bricks as solid: most pixels agree closely, all are an image of the same scene
+    assert np.mean(np.abs(rp.astype(np.int32) - px.astype(np.int32)) <= 8) > 0.9
 
 
 def test_cpp_multi_gpu_example_with_one_rank(bm, torch_cuda, tmp_path):
