@@ -89,7 +89,11 @@ struct FrameConstants {
 	float* accum;          // float4 per pixel of the shard
 	uint32_t* dbg;         // hit records, 8 words per pixel, or null
 	int frames_after;      // 0: the launch's last frame
-	int reserved_;
+	// uniform launches (read from the FIRST frame's constants): all frames share everything but sample_base and buffers, which step by
+	// constants -- then every entry carries the first frame's sample_base / buffers and a lane adds its frame's offsets itself
+	int ring_uniform;
+	int ring_sample_stride;      // sample_base of frame i = sample_base + i * ring_sample_stride
+	uint32_t ring_pixel_stride;  // pixel record of frame i = accum + (local pixel + i * ring_pixel_stride) float4s
 };
 
 struct DeviceCounters { // v: same order as bm_counters; sched: same order as bm_sched_stats

@@ -1034,6 +1034,33 @@ int Scene::render_frames(int count, const bm_camera* cams, const bm_frame_params
 				}
 			}
 	}
+	// ---- a UNIFORM launch?  Frames that differ only in sample_base and buffers, both stepping by constants (a resting camera: the
+	// reference's progressive accumulation; bench.py's steps; a rank's batch into one allocation): lanes of consecutive frames may then
+	// share a wave (trace.hip), because nothing a lane reads after it took its item depends on the frame any more.
+	if (count > 1 && !hit_records) {
+		auto same_view = [&](const FrameConstants& a, const FrameConstants& b) {
+			// everything up to `width` is the view, the sun and the sky (device_types.h); base_frame seeds the RNG
+			return std::memcmp(&a, &b, offsetof(FrameConstants, width)) == 0 && a.base_frame == b.base_frame;
+		};
+		const long long sample_stride = static_cast<long long>(fcs[1].sample_base) - fcs[0].sample_base;
+		const long long byte_stride = reinterpret_cast<const char*>(accums[1]) - reinterpret_cast<const char*>(accums[0]);
+		const unsigned long long pixels = static_cast<unsigned long long>(fc.local_rows) * static_cast<unsigned long long>(fc.width);
+		bool uniform = sample_stride >= 0 && sample_stride < (1 << 20) && byte_stride >= 0 && byte_stride % 16 == 0 &&
+					   static_cast<unsigned long long>(byte_stride / 16) * static_cast<unsigned long long>(count - 1) + pixels < (1ull << 32) &&
+					   static_cast<long long>(fcs[0].sample_base) + sample_stride * (count - 1) + fc.spp < (1ll << 31);
+		for (int i = 1; i < count && uniform; ++i)
+			uniform = same_view(fcs[static_cast<size_t>(i)], fcs[0]) && static_cast<long long>(fcs[static_cast<size_t>(i)].sample_base) == fcs[0].sample_base + sample_stride * i &&
+					  reinterpret_cast<const char*>(accums[i]) == reinterpret_cast<const char*>(accums[0]) + byte_stride * i;
+		if (uniform) {
+			for (int i = 0; i < count; ++i) { // every entry reads like the first; the frame is an offset the lanes add themselves
+				fcs[static_cast<size_t>(i)].sample_base = fcs[0].sample_base;
+				fcs[static_cast<size_t>(i)].accum = fcs[0].accum;
+			}
+			fcs[0].ring_uniform = 1;
+			fcs[0].ring_sample_stride = static_cast<int>(sample_stride);
+			fcs[0].ring_pixel_stride = static_cast<uint32_t>(byte_stride / 16);
+		}
+	}
 	BM_HIP(hipSetDevice(device_));
 	// `stream` is used as given: nullptr is HIP's default stream (what the reference's <<<>>> launches use), which is
 	// ordered with the caller's other default-stream work (e.g. torch's fill kernels on the accumulation buffer).

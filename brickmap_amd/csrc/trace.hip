@@ -275,10 +275,15 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		// ---- refill: hand pixels to idle lanes, BM_ITEM_LANES at a time (consecutive tickets walk through a 4x4 chunk)
 		const unsigned long long idle = __ballot(state == ST_IDLE);
 		const int nI = __popcll(idle);
-		if (RING && !work_left && nI == 64 && fc.frames_after > 0) {
+		if (RING && !work_left && (nI == 64 || fg.ring_uniform) && fc.frames_after > 0) {
 			// this wave has nothing left to do in its frame: on to the next frame of the launch (its constants, its buffers, its own
 			// ticket counters).  Every lane is idle here, helpers included, so nothing of the old frame is in flight in this wave;
 			// other waves may still be tracing it.
+			// UNIFORM launches (FrameConstants::ring_uniform: the frames share view, sun and base_frame; their sample_base and buffers
+			// step by constants -- a resting camera accumulating, the reference's own steady state, main.cpp:117-147 with no input) do not
+			// even wait for that: a lane's frame is folded into its sample index and its pixel offset when it takes its item
+			// (refill, below), every other constant is the same in all frames, so lanes of two frames share the wave and the
+			// wave never runs empty between frames -- only at the end of the launch.
 			++ring_pos;
 			accum = reinterpret_cast<float4*>(fc.accum);
 			if (DBG) dbg = fc.dbg;
@@ -304,6 +309,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 										  ? (total_units - static_cast<uint32_t>(my_counter) + kCounters - 1u) / kCounters : 0u;
 			const uint32_t my_tickets = my_units * (xcd_handout ? kStChunks : 4u) * items_per_chunk; // consecutive tickets = the samples of one chunk
 			const uint32_t counter_now = static_cast<uint32_t>(my_counter);
+			const int ring_at_refill = RING ? ring_pos : 0;
 			if (base + want >= my_tickets) { // this counter is used up: move to the next one (helping out), or finish
 				my_counter = (my_counter + 1) % static_cast<int>(kCounters);
 				if (++counters_done >= static_cast<int>(kCounters)) { work_left = false; if (BM_TIMED) t_dry = __builtin_amdgcn_s_memtime(); }
@@ -347,6 +353,11 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						xy = static_cast<uint32_t>(x) | (static_cast<uint32_t>(y) << 16);
 						s = sample_items ? static_cast<int>(item_sample) : 0;
 						s_end = sample_items ? s + 1 : fg.spp;
+						if (RING) { // uniform launches: the frame as an offset of the sample index and of the pixel record (strides are 0 otherwise)
+							const int sample_off = __mul24(ring_at_refill, fg.ring_sample_stride);
+							s += sample_off; s_end += sample_off;
+							local_pixel += static_cast<uint32_t>(ring_at_refill) * fg.ring_pixel_stride;
+						}
 						pstate = P_GEN;
 						state = ST_NEED;
 						if (!HELP) acc = atomic_acc ? make_float4(0.f, 0.f, 0.f, 0.f) : pixel_load(accum + local_pixel);

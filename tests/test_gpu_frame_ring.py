@@ -85,6 +85,49 @@ def test_production_frames_of_one_launch_share_a_buffer(bm, orc, torch_cuda, sce
         assert_radiance(a, oacc)
 
 
+def test_uniform_launch_mixes_frames_inside_a_wave(bm, orc, torch_cuda, scene256, world256):
+    """A UNIFORM launch -- one view, sample_base and buffers stepping by constants (a resting camera; a rank's batch in one allocation):
+    lanes of consecutive frames share a wave (the frame is folded into the lane's sample index and pixel offset).  Ordered frames into one
+    allocation are still the single launches bit for bit; the same frames into scattered buffers (not uniform: waves switch frame by
+    frame) give the same bits; sample strides other than spp, (chunk, sample) items and a shard included."""
+    torch = torch_cuda
+    cam, ocam = cameras(bm, orc, 256)
+    for (W, H, K, spp, stride, extra) in ((150, 100, 6, 1, 1, {}), (97, 61, 5, 2, 7, {}), (128, 96, 4, 3, 3, dict(flags=bm.BM_FLAG_SAMPLE_ITEMS)),
+                                          (160, 100, 4, 2, 2, dict(band_rows=8, shard_rank=1, shard_count=3, flags=bm.BM_FLAG_SAMPLE_ITEMS))):
+        ordered = not extra.get("flags", 0) & bm.BM_FLAG_SAMPLE_ITEMS
+        flags = extra.get("flags", 0) | (bm.BM_FLAG_ORDERED if ordered else 0)
+        kw = {k: v for k, v in extra.items() if k != "flags"}
+        params = [bm.FrameParams(W, H, spp=spp, sample_base=11 + stride * k, max_bounces=3, flags=flags, **kw) for k in range(K)]
+        rows = bm.local_rows(params[0])
+        batch = torch.zeros((K, rows, W, 4), dtype=torch.float32, device="cuda:0")       # one allocation: uniform
+        scene256.render_frames(cam, params, [batch[k] for k in range(K)])
+        scattered = [torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda:0") for _ in range(K)]  # separate allocations: not uniform
+        pad = [torch.zeros(1000 * (k + 1), device="cuda:0") for k in range(K)]  # (keep the allocator from spacing them evenly)
+        scene256.render_frames(cam, params, scattered)
+        torch.cuda.synchronize()
+        for k in range(K):
+            single = torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda:0")
+            scene256.render(cam, params[k], single)
+            torch.cuda.synchronize()
+            if ordered:
+                assert torch.equal(batch[k].view(torch.int32), single.view(torch.int32)), f"uniform launch, frame {k}"
+                assert torch.equal(scattered[k].view(torch.int32), single.view(torch.int32)), f"frame-by-frame launch, frame {k}"
+            else:
+                for got in (batch[k], scattered[k]):
+                    assert torch.equal(got[..., 3], single[..., 3])
+                    np.testing.assert_allclose(got[..., :3].cpu().numpy(), single[..., :3].cpu().numpy(), rtol=2e-5, atol=1e-7)
+        del pad
+    # the bench's shape against the oracle: K production frames of one view into ONE buffer = the oracle's K-sample frame
+    W, H, K = 200, 120, 8
+    ring = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    scene256.render_frames(cam, [bm.FrameParams(W, H, spp=1, sample_base=k, max_bounces=3) for k in range(K)], ring)
+    torch.cuda.synchronize()
+    world256.reset_device(True)
+    oacc, _, _, _ = world256.render(ocam, orc.make_frame(W, H, spp=K, max_bounces=3), want_dbg=False)
+    assert np.all(ring[..., 3].cpu().numpy() == K)
+    assert_radiance(ring.cpu().numpy(), oacc)
+
+
 def test_counters_of_a_launch_are_the_sum_of_its_frames(bm, orc, torch_cuda, scene256, world256):
     """BM_FLAG_COUNTERS on every frame of a launch: the traversal counters are the oracle's, summed over the frames (the instrumented
     instantiation with helper lanes walks the ring like the plain one)."""

@@ -36,12 +36,13 @@ def test_production_kernel_keeps_its_register_budget_and_its_shape(KERNEL, listi
     def field(name):
         return int(re.search(name + r": (\d+)", block).group(1))
 
-    helpers = KERNEL.endswith(("Lb1ELb0E", "Lb1ELb1E"))  # the default of production frames; the ordered instantiations keep an accumulator (4 more registers)
     ring = KERNEL.endswith("ELb1E")
+    helpers = KERNEL.endswith(("Lb1ELb0E", "Lb1ELb1E"))  # the default of production frames; the ordered instantiations keep an accumulator (4 more registers)
     assert field("VGPRs") <= 72 and field(r"Occupancy \[waves/SIMD\]") == 7, "more than 72 VGPRs: 6 waves per SIMD instead of 7"
     # what is spilled at seven waves are two loop-invariant constants of a cold branch (rays that start outside the world) in the
     # helper-lane instantiations; the ordered ones spill two more
-    assert field("VGPRs Spill") <= (2 if helpers else 4) and field(r"ScratchSize \[bytes/lane\]") <= (8 if helpers else 16)
+    # (the ordered instantiation of a multi-frame launch -- a verification path, never the timed one -- spills one word more)
+    assert field("VGPRs Spill") <= (2 if helpers else 4) and field(r"ScratchSize \[bytes/lane\]") <= (8 if helpers else (20 if ring else 16))
     assert field(r"LDS Size \[bytes/block\]") == 16384
     # the scheduler loop runs at the limit of the scalar file: a spilled scalar is a v_readlane / v_writelane in the hot loop.  The
     # frame ring's extra loop-carried scalar costs a few (which is why single-frame launches have an instantiation of their own):
