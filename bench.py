@@ -397,7 +397,7 @@ def main():
 
     # ---- the north-star target shape (BASELINE.json: "1080p, 4 spp, 4-bounce"), N = 1 / config 2 only, reported next to the
     # headline, never as `value`: the same frame at 4 samples per pixel with (chunk, sample) work items -- one launch per frame, and
-    # five consecutive frames as one launch
+    # consecutive frames as one launch (as many as the headline's steps, at most 20)
     target4 = None
     if not multi and args.workload == "config2" and not streaming and extras:
         n4 = 5
@@ -408,11 +408,12 @@ def main():
         scene.render(cam, p4(2, flags=bm.BM_FLAG_COUNTERS), scratch)
         c4 = scene.counters()
         b4 = 4 * c4["index_loads"] + 64 * c4["brick_tests"] + 16 * W * H
-        r4 = measure(lambda i: scene.render_frames(cam, [p4(n4 * i + k) for k in range(n4)], scratch), 1) / n4
+        nr = max(n4, min(args.steps, 20))  # (as many frames per launch as the headline's steps)
+        r4 = measure(lambda i: scene.render_frames(cam, [p4(nr * i + k) for k in range(nr)], scratch), 1) / nr
         target4 = {"workload": f"{W}x{H}, 4 spp, {segments} segments/path, (chunk, sample) work items", "ms_per_step": round(s4 * 1e3, 4),
                    "Mrays_s": round(W * H * 4 * segments / s4 / 1e6, 1), "kernel_ms_avg": round(k4 * 1e3, 4),
                    "roofline_frac": round(b4 / k4 / 1e9 / HBM_PEAK_GBS, 5),
-                   "frame_ring": {"frames_per_launch": n4, "ms_per_step": round(r4 * 1e3, 4), "Mrays_s": round(W * H * 4 * segments / r4 / 1e6, 1),
+                   "frame_ring": {"frames_per_launch": nr, "ms_per_step": round(r4 * 1e3, 4), "Mrays_s": round(W * H * 4 * segments / r4 / 1e6, 1),
                                   "roofline_frac": round(b4 / r4 / 1e9 / HBM_PEAK_GBS, 5)}}
 
     # ---- the denominator of a scaling efficiency: the N > 1 lines strong-scale ONE fixed job (the frame at spp_total samples,

@@ -208,7 +208,7 @@ def test_default_bench_line_schema():
     one = out["one_frame_per_launch"]
     assert one["ms_per_step"] > 0 and one["kernel_ms_avg"] > 0 and 0 < one["roofline_frac"] < 1
     n4 = out["north_star_4spp"]
-    assert n4["roofline_frac"] > 0 and n4["frame_ring"]["ms_per_step"] > 0 and n4["frame_ring"]["frames_per_launch"] == 5
+    assert n4["roofline_frac"] > 0 and n4["frame_ring"]["ms_per_step"] > 0 and n4["frame_ring"]["frames_per_launch"] == 5  # (max(5, steps))
     job = out["multi_gpu_job_on_one_gpu"]
     assert job["ms_per_step"] > 0 and job["one_frame_per_launch"]["ms_per_step"] > 0
     # the scaling prediction the first real multi-GPU run is checked against: every rank's shard of the 8-spp job at N = 2 / 4 / 8, ONE stream
