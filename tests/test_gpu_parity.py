@@ -589,8 +589,8 @@ def test_errors_are_reported_not_fatal(bm, torch_cuda):
     assert L.bm_scene_create(0, 100, 128, C.byref(h)) == 10001 and b"multiples of 128" in L.bm_last_error_string()
     # a ray's cell is one 32-bit offset into the padded cube field, candidates take 24-bit products of brick coordinates: larger worlds
     # are refused, not mis-traced
-    assert L.bm_scene_create(0, 8192 + 128, 128, C.byref(h)) == 10001 and b"not supported" in L.bm_last_error_string()
-    assert L.bm_scene_create(0, 1024, 8192 + 128, C.byref(h)) == 10001 and b"not supported" in L.bm_last_error_string()
+    assert L.bm_scene_create(0, 8192 + 128, 128, C.byref(h)) == 10001 and b"world too large" in L.bm_last_error_string()
+    assert L.bm_scene_create(0, 1024, 8192 + 128, C.byref(h)) == 10001 and b"world too large" in L.bm_last_error_string()
     assert L.bm_scene_create(0, 8192, 8192, C.byref(h)) == 10001 and b"4 GiB" in L.bm_last_error_string()
     s = bm.Scene(128, 128, device=0)
     with pytest.raises(bm.BrickmapError):
