@@ -198,10 +198,16 @@ def main():
 
     # ---- how the steps are issued: the frame ring (module docstring).  Streaming workloads service their brick requests between
     # launches (bm_scene_process_load_queue): one step per launch there.
+    # The ring pays where a frame's end is a visible part of it: the multi-frame instantiation carries one more scalar round the scheduler
+    # loop (+2.6 % per frame) and gives back ~0.15 ms per frame -- a win below ~5 ms per frame (1080p up to 8 spp), a loss on
+    # the 8K / 4K workloads (config 5: 99.3 ms per frame in a ring of five against 96.3 as single launches).
+    ring_pays = W * state.local_rows * spp_rank <= (1 << 24)
     if streaming:
         per_launch = 1
     elif args.frames_per_launch > 0:
         per_launch = min(args.frames_per_launch, 256)
+    elif not ring_pays:
+        per_launch = 1
     elif by_rows:
         per_launch = min(MULTI_FRAMES_PER_LAUNCH, max(args.steps, 1))
     else:
@@ -424,6 +430,11 @@ def main():
     same_job = None
     job_spp = spp_total if multi else (max(args.multi_gpu_spp, 1) if args.workload == "config2" else spp * 8)
     nj = MULTI_FRAMES_PER_LAUNCH
+
+    def steps_per_launch(rows, samples):
+        """how a rank issues a job of `rows` x W pixels at `samples` spp: the frame ring where it pays (see ring_pays above)"""
+        return nj if W * rows * samples <= (1 << 24) else 1
+
     if rank == 0 and not streaming and extras:
         try:
             whole = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
@@ -431,9 +442,10 @@ def main():
             reps = 2 if W * H * job_spp < 100e6 else 1
             s_one = measure(lambda i: scene.render(cam, pj(i), whole), 3, reps=reps)
             k_one = float(np.mean(scene.render_times(3)))
-            s_ring = measure(lambda i: scene.render_frames(cam, [pj(nj * i + k) for k in range(nj)], whole), 1, reps=reps) / nj
+            nw = steps_per_launch(H, job_spp)
+            s_ring = measure(lambda i: scene.render_frames(cam, [pj(nw * i + k) for k in range(nw)], whole), 1, reps=reps) / nw if nw > 1 else s_one
             same_job = {"workload": f"{W}x{H}, {job_spp} spp, {segments} segments/path, (chunk, sample) work items, unsharded on one GPU",
-                        "ms_per_step": round(s_ring * 1e3, 4), "Mrays_s": round(W * H * job_spp * segments / s_ring / 1e6, 1), "frames_per_launch": nj,
+                        "ms_per_step": round(s_ring * 1e3, 4), "Mrays_s": round(W * H * job_spp * segments / s_ring / 1e6, 1), "frames_per_launch": nw,
                         "one_frame_per_launch": {"ms_per_step": round(s_one * 1e3, 4), "kernel_ms_avg": round(k_one, 4)}}
             del whole
         except Exception as e:  # noqa: BLE001 -- an extra: must not cost the headline measurement
@@ -449,7 +461,7 @@ def main():
     shard_pred = None
     if not multi and not streaming and extras and same_job is not None and "ms_per_step" in same_job:
         try:
-            shard_pred = {"job": same_job["workload"], "frames_per_launch": nj, "unsharded_ms_per_step": same_job["ms_per_step"],
+            shard_pred = {"job": same_job["workload"], "frames_per_launch": steps_per_launch(state.local_rows // 8, job_spp), "unsharded_ms_per_step": same_job["ms_per_step"],
                           "unsharded_ms_per_step_one_frame_per_launch": same_job["one_frame_per_launch"]["ms_per_step"],
                           "shard_ms_per_step": {}, "predicted_speedup": {}, "shard_ms_per_step_one_frame_per_launch": {}, "predicted_speedup_one_frame_per_launch": {},
                           "per_rank_ms_per_step": {}, "band_rows": band,
@@ -462,8 +474,9 @@ def main():
                     ps = lambda i: bm.FrameParams(W, H, spp=job_spp, sample_base=7000 + i * job_spp, max_bounces=max_bounces, flags=bm.BM_FLAG_SAMPLE_ITEMS,
                                                   band_rows=band, shard_rank=r, shard_count=n_ranks)
                     reps = 2 if W * H * job_spp < 100e6 else 1
-                    ring_ms.append(measure(lambda i: scene.render_frames(cam, [ps(nj * i + k) for k in range(nj)], st.blit_buffer), 1, reps=reps) / nj * 1e3)
                     one_ms.append(measure(lambda i: scene.render(cam, ps(i), st.blit_buffer), 4, reps=reps) * 1e3)
+                    ns = steps_per_launch(st.local_rows, job_spp)
+                    ring_ms.append(measure(lambda i: scene.render_frames(cam, [ps(ns * i + k) for k in range(ns)], st.blit_buffer), 1, reps=reps) / ns * 1e3 if ns > 1 else one_ms[-1])
                     del st
                 key = str(n_ranks)
                 shard_pred["per_rank_ms_per_step"][key] = [round(t, 4) for t in ring_ms]
