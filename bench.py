@@ -198,9 +198,9 @@ def main():
 
     # ---- how the steps are issued: the frame ring (module docstring).  Streaming workloads service their brick requests between
     # launches (bm_scene_process_load_queue): one step per launch there.
-    # The ring pays where a frame's end is a visible part of it: the multi-frame instantiation carries one more scalar round the scheduler
-    # loop (+2.6 % per frame) and gives back ~0.15 ms per frame -- a win below ~5 ms per frame (1080p up to 8 spp), a loss on
-    # the 8K / 4K workloads (config 5: 99.3 ms per frame in a ring of five against 96.3 as single launches).
+    # The ring pays where a frame's end is a visible part of it: it gives back ~0.2 ms per frame, and the multi-frame instantiations spill a
+    # few scalars more than the one-frame kernel -- a win at 1080p up to 8 spp (1.00 -> 0.77 ms, 3.24 -> 2.98, 6.22 -> 6.1), nothing on the
+    # 8K / 4K workloads (config 5: 96.9 ms per frame in a ring of five against 96.1 as single launches).
     ring_pays = W * state.local_rows * spp_rank <= (1 << 24)
     if streaming:
         per_launch = 1

@@ -6,7 +6,7 @@
 
 namespace bm {
 constexpr size_t kWorkCounterBytes = 64 * 32 * sizeof(uint32_t); // up to 64 chunk counters, one 128-byte line each
-int trace_blocks_per_cu(bool instrumented, bool xcd_handout, bool helpers, bool ring = false); // resident workgroups per CU of that instantiation (ring: a launch of several frames)
+int trace_blocks_per_cu(bool instrumented, bool xcd_handout, bool helpers, int ring = 0); // resident workgroups per CU of that instantiation (ring: 0 = a launch of one frame, 1 = of several, 2 = of several uniform ones)
 // blocks_per_cu_cap: 0 = as many workgroups per CU as the instantiation keeps resident; > 0 = at most that many (tuning runs)
 // fc_dev[0], fc_dev[1], ... are the constants of the frames of this launch (the frame ring, trace.hip; the last entry has frames_after == 0): each
 // names its own accumulation / hit-record buffers; work_counter is the first of as many zeroed blocks of kWorkCounterBytes; fc = host copy of fc_dev[0]

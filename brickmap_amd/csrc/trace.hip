@@ -138,11 +138,14 @@ enum : int { ST_IDLE = 4, ST_CONN = 5 };
 // (kernel.cu:341-343).  The rays traced are the same rays; what changes is who walks them: idle lanes do useful work without a
 // refill, and a path's latency -- which is what the end of a frame waits for -- is its extend rays' alone.  Pixels are therefore
 // written back with atomics as well (the accumulator starts at zero in the lane), so radiance is equal up to summation order.
-// RING: the launch may hold more than one frame (the frame ring, below).  An instantiation of its own because the scheduler loop runs
+// RING: 0 = a launch of one frame; 1 = several frames, a wave changes frame when all its lanes are idle; 2 = several frames of a
+// UNIFORM launch, whose lanes carry their frame themselves (below) -- then every constant is read from the first frame's entry, at a
+// fixed address, and the frame's index is only needed where a wave takes items.
+// The launch may hold more than one frame (the frame ring, below).  An instantiation of its own because the scheduler loop runs
 // at the limit of the scalar register file: the ring's one extra loop-carried scalar and the indexed constants cost a single-frame
 // launch 2.6 % (config 2 1.005 -> 1.031 ms, config 3 19.8 -> 20.4; four more spilled scalars in the hot loop), which a launch of
 // ONE frame has no reason to pay.
-template <bool DBG, bool XCD = false, bool HELP = false, bool RING = false>
+template <bool DBG, bool XCD = false, bool HELP = false, int RING = 0>
 // (the instrumented variant carries hit records and counters: it gets the registers instead of the occupancy)
 __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(const DeviceScene sc, const FrameConstants* __restrict__ fcp,
 												  DeviceCounters* __restrict__ counters, uint32_t* __restrict__ work_counter) {
@@ -168,7 +171,10 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	// round the loop: only then does the compiler prove that the kernel's stores leave the constants alone (scalar loads).
 	const FrameConstants& fg = *fcp;     // what all frames of the launch share
 	int ring_pos = 0;                    // the frame of the launch this wave is in (RING; otherwise the constant 0)
-#define fc (fcp[RING ? ring_pos : 0])
+	constexpr bool kRing = RING != 0, kUniform = RING == 2;
+#define fc (fcp[RING == 1 ? ring_pos : 0])
+	// are there frames after the one this wave is in?  (uniform: the first entry knows how many follow IT)
+	auto more_frames = [&]() { return kUniform ? ring_pos < fg.frames_after : fc.frames_after > 0; };
 	float4* accum = reinterpret_cast<float4*>(fc.accum);
 	uint32_t* dbg = DBG ? fc.dbg : nullptr;
 	__shared__ unsigned long long lds_brick[8 * 256]; // 16 KiB: one 64-byte brick per thread (traverse.h brick_dma_to_lds: word k of thread t at u32 word k * 256 + t)
@@ -229,7 +235,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		else acc.w += 1.f;
 	};
 
-	bool work_left = true;
+	typename std::conditional<RING == 1, int, bool>::type work_left = 1; // (a bool where two states do: as an int it cost the one-frame kernel three spilled vector registers)
+	// 1: the frame has tickets left; 0: the launch has none; 2 (RING == 1): the frame is used up, the next one starts once every lane is idle
 	constexpr uint32_t kCounters = XCD ? 8u : BM_WORK_COUNTERS, kCounterStride = 32; // one 128-byte line per counter
 	// (the wave index is the same in all 64 lanes; saying so keeps everything derived from it -- the counter in use, `work_left`,
 	// the loop's exit conditions -- in scalar registers and the scheduler loop's branches scalar)
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 	// turns the scheduler loop's branches into exec-mask branches)
 	auto round_budget = [&]() {
 		const long long budget = (static_cast<long long>(total_chunks) + 64) * (static_cast<long long>(fg.spp) + 1) * (fg.max_bounces + 2) *
-								 (2ll * sc.cells + sc.cells_height + 64);
+								 (2ll * sc.cells + sc.cells_height + 64) * (kRing ? fg.frames_after + 1 : 1); // (all frames of the launch: computed once, nothing of it lives across the loop)
 		return static_cast<long long>((static_cast<unsigned long long>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(budget >> 32)))) << 32) |
 									  static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(budget))));
 	};
@@ -275,24 +282,20 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		// ---- refill: hand pixels to idle lanes, BM_ITEM_LANES at a time (consecutive tickets walk through a 4x4 chunk)
 		const unsigned long long idle = __ballot(state == ST_IDLE);
 		const int nI = __popcll(idle);
-		if (RING && !work_left && (nI == 64 || fg.ring_uniform) && fc.frames_after > 0) {
+		if (RING == 1 && work_left == 2 && nI == 64) {
 			// this wave has nothing left to do in its frame: on to the next frame of the launch (its constants, its buffers, its own
 			// ticket counters).  Every lane is idle here, helpers included, so nothing of the old frame is in flight in this wave;
-			// other waves may still be tracing it.
-			// UNIFORM launches (FrameConstants::ring_uniform: the frames share view, sun and base_frame; their sample_base and buffers
-			// step by constants -- a resting camera accumulating, the reference's own steady state, main.cpp:117-147 with no input) do not
-			// even wait for that: a lane's frame is folded into its sample index and its pixel offset when it takes its item
-			// (refill, below), every other constant is the same in all frames, so lanes of two frames share the wave and the
-			// wave never runs empty between frames -- only at the end of the launch.
+			// other waves may still be tracing it.  (Whether there IS a next frame was settled when the counters ran dry, below: a
+			// test of the constants here, or in the loop's exit condition, is a scalar load and a wait in EVERY scheduler round --
+			// that was the ring's 2.6 % per frame.)
 			++ring_pos;
 			accum = reinterpret_cast<float4*>(fc.accum);
 			if (DBG) dbg = fc.dbg;
 			my_counter = first_counter();
 			counters_done = 0;
-			work_left = true;
-			rounds_left = round_budget();
+			work_left = 1;
 		}
-		if (work_left && nI >= fg.refill_min) {
+		if (work_left == 1 && nI >= fg.refill_min) {
 			// One global word serves only ~90 returning atomics per microsecond chip-wide, and a refill stalls the whole
 			// wave until its atomic returns; with thousands of waves on one counter that queue is tens of microseconds
 			// long.  The chunk sequence is therefore dealt to kCounters interleaved counters (8x8-pixel groups of four
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			// the image top-down, so concurrently running waves keep working on neighbouring rows of the image.
 			const int want = nI / BM_ITEM_LANES;
 			uint32_t base = 0;
-			if (lane == 0) base = atomicAdd(work_counter + (RING ? static_cast<uint32_t>(ring_pos) * static_cast<uint32_t>(kWorkCounterBytes / sizeof(uint32_t)) : 0u) + my_counter * kCounterStride, static_cast<uint32_t>(want));
+			if (lane == 0) base = atomicAdd(work_counter + (kRing ? static_cast<uint32_t>(ring_pos) * static_cast<uint32_t>(kWorkCounterBytes / sizeof(uint32_t)) : 0u) + my_counter * kCounterStride, static_cast<uint32_t>(want));
 			base = __builtin_amdgcn_readfirstlane(base);
 			// units dealt to the counters: groups of four chunks, or whole super-tiles
 			const uint32_t st_x = (static_cast<uint32_t>(fg.tiles_x) + kXcdTiles - 1u) / kXcdTiles, st_y = (static_cast<uint32_t>(fg.tiles_y) + kXcdTiles - 1u) / kXcdTiles;
@@ -309,10 +312,23 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 										  ? (total_units - static_cast<uint32_t>(my_counter) + kCounters - 1u) / kCounters : 0u;
 			const uint32_t my_tickets = my_units * (xcd_handout ? kStChunks : 4u) * items_per_chunk; // consecutive tickets = the samples of one chunk
 			const uint32_t counter_now = static_cast<uint32_t>(my_counter);
-			const int ring_at_refill = RING ? ring_pos : 0;
+			const int ring_at_refill = kRing ? ring_pos : 0;
 			if (base + want >= my_tickets) { // this counter is used up: move to the next one (helping out), or finish
 				my_counter = (my_counter + 1) % static_cast<int>(kCounters);
-				if (++counters_done >= static_cast<int>(kCounters)) { work_left = false; if (BM_TIMED) t_dry = __builtin_amdgcn_s_memtime(); }
+				if (++counters_done >= static_cast<int>(kCounters)) {
+					// the frame's tickets are gone.  UNIFORM launches (FrameConstants::ring_uniform: the frames share view, sun and base_frame;
+					// their sample_base and buffers step by constants -- a resting camera accumulating, the reference's own steady state,
+					// main.cpp:117-147 with no input) go straight on: a lane's frame is folded into its sample index and its pixel offset
+					// when it takes its item (below), every other constant is the same in all frames, so lanes of two frames share
+					// the wave and the wave never runs empty between frames -- only at the end of the launch.
+					if (kRing && more_frames()) {
+						if (kUniform) { ++ring_pos; my_counter = first_counter(); counters_done = 0; }
+						else work_left = 2;
+					} else {
+						work_left = 0;
+						if (BM_TIMED) t_dry = __builtin_amdgcn_s_memtime();
+					}
+				}
 			}
 			const int rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(idle >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(idle), 0u));
 			if (state == ST_IDLE && rank < want * BM_ITEM_LANES) {
@@ -353,7 +369,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 						xy = static_cast<uint32_t>(x) | (static_cast<uint32_t>(y) << 16);
 						s = sample_items ? static_cast<int>(item_sample) : 0;
 						s_end = sample_items ? s + 1 : fg.spp;
-						if (RING) { // uniform launches: the frame as an offset of the sample index and of the pixel record (strides are 0 otherwise)
+						if (kUniform) { // the frame as an offset of the sample index and of the pixel record
 							const int sample_off = __mul24(ring_at_refill, fg.ring_sample_stride);
 							s += sample_off; s_end += sample_off;
 							local_pixel += static_cast<uint32_t>(ring_at_refill) * fg.ring_pixel_stride;
@@ -376,8 +392,8 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 		const int nC = __popcll(__ballot(state == ST_NEED) | __ballot(state == ST_CONN)); // shade / generate, and connect (same pass)
 		const int live = nA + nB + nC;
 		--rounds_left;
-		if (rounds_left < 0 || (live == 0 && !work_left && (!RING || fc.frames_after <= 0))) break;
-		// (live == 0 with frames left: the next round starts the next frame, see the top of the loop)
+		if (rounds_left < 0 || (live == 0 && work_left == 0)) break;
+		// (live == 0 with work_left == 2: the next round starts the next frame, see the top of the loop)
 		// (live == 0 with chunks left: only pixels outside the image were handed out; the passes below find nothing to do)
 		// Policy: an expensive phase runs once a quarter of the live lanes wait for it, the cheap connect phase
 		// once an eighth does; otherwise the DDA keeps moving.  With no lane left in the DDA the largest group runs.
@@ -821,7 +837,7 @@ __global__ void debug_sky_kernel(const FrameConstants fc, int n, const float* __
 
 // ---- host-callable launchers (kernels.h)
 // resident 256-thread workgroups per compute unit of one instantiation (asked once per instantiation)
-template <bool DBG, bool XCD, bool HELP, bool RING>
+template <bool DBG, bool XCD, bool HELP, int RING>
 static int occupancy_of() {
 	static const int cached = [] {
 		int n = 0;
@@ -830,15 +846,16 @@ static int occupancy_of() {
 	}();
 	return cached;
 }
-// run `f` with the four instantiation choices as compile-time constants
+// run `f` with the four instantiation choices as compile-time constants (ring: 0 = one frame, 1 = frame ring, 2 = uniform frame ring)
 template <class F>
-static auto with_instantiation(bool instrumented, bool xcd, bool help, bool ring, F&& f) {
-	auto pick = [&](auto d, auto x, auto h) { return ring ? f(d, x, h, std::true_type{}) : f(d, x, h, std::false_type{}); };
+static auto with_instantiation(bool instrumented, bool xcd, bool help, int ring, F&& f) {
+	using R0 = std::integral_constant<int, 0>; using R1 = std::integral_constant<int, 1>; using R2 = std::integral_constant<int, 2>;
+	auto pick = [&](auto d, auto x, auto h) { return ring == 2 ? f(d, x, h, R2{}) : (ring == 1 ? f(d, x, h, R1{}) : f(d, x, h, R0{})); };
 	auto pick_h = [&](auto d, auto x) { return help ? pick(d, x, std::true_type{}) : pick(d, x, std::false_type{}); };
 	auto pick_x = [&](auto d) { return xcd ? pick_h(d, std::true_type{}) : pick_h(d, std::false_type{}); };
 	return instrumented ? pick_x(std::true_type{}) : pick_x(std::false_type{});
 }
-int trace_blocks_per_cu(bool instrumented, bool xcd, bool help, bool ring) {
+int trace_blocks_per_cu(bool instrumented, bool xcd, bool help, int ring) {
 	return with_instantiation(instrumented, xcd, help, ring, [](auto d, auto x, auto h, auto r) { return occupancy_of<decltype(d)::value, decltype(x)::value, decltype(h)::value, decltype(r)::value>(); });
 }
 
@@ -850,7 +867,8 @@ void launch_trace(const DeviceScene& sc, const FrameConstants& fc, const FrameCo
 				  uint32_t* work_counter, bool instrumented, int compute_units, int blocks_per_cu_cap, hipStream_t stream) {
 	const long long chunks = static_cast<long long>(fc.tiles_x) * fc.tiles_y * 16;
 	if (chunks <= 0) return;
-	const bool xcd = fc.xcd_handout != 0, help = fc.helpers != 0, ring = fc.frames_after > 0;
+	const bool xcd = fc.xcd_handout != 0, help = fc.helpers != 0;
+	const int ring = fc.frames_after > 0 ? (fc.ring_uniform ? 2 : 1) : 0;
 	int per_cu = trace_blocks_per_cu(instrumented, xcd, help, ring); // what THIS instantiation keeps resident
 	if (blocks_per_cu_cap > 0 && per_cu > blocks_per_cu_cap) per_cu = blocks_per_cu_cap;
 	const long long resident_blocks = static_cast<long long>(compute_units) * per_cu;
