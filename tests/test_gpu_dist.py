@@ -129,7 +129,7 @@ def test_bench_big_multi_gpu_workloads_dry_run_with_one_rank(workload):
     assert out["n_gpus"] == 1 and out["value"] > 0
     assert out["config"]["spp_per_step"] == (16 if workload == "config4" else 32)
     assert out["ranks"]["communicator_world"] == 1 and out["ranks"]["process_group_backend"] == "nccl" and "C-ABI" in out["config"]["exchange"]
-    assert "trace_paths<false, true, true, false>" in out["roofline"]["kernel"]  # the XCD-aware hand-out of big frames, helper lanes, one step = one launch
+    assert "trace_paths<false, true, true, 0>" in out["roofline"]["kernel"]  # the XCD-aware hand-out of big frames, helper lanes, one step = one launch
 
 
 def test_bench_config4_with_two_ranks_on_one_gpu(tmp_path):
@@ -198,7 +198,7 @@ def test_default_bench_line_schema():
     assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     assert "reference-equivalent" in rf["achieved_is"] and "VALU" in rf["limiter"] and "pmc_summary_config2" in rf["limiter_source"]
     assert rf["kernel_ms_per_step"] <= out["ms_per_step"] * 1.05 and abs(rf["kernel_ms_avg"] - rf["kernel_ms_per_step"] * 3) < 1e-3  # ONE launch of three frames
-    assert rf["launches"] == 1 and rf["frames_per_launch"] == [3] and rf["kernel"] == "bm::trace_paths<false, false, true, true>"
+    assert rf["launches"] == 1 and rf["frames_per_launch"] == [3] and rf["kernel"] == "bm::trace_paths<false, false, true, 2>"
     assert rf["traffic"] and "_pmc_summary_config2.json" in rf["traffic_source"] and rf["traffic"] == 3 * rf["traffic_per_step"]
     # self-describing: occupancy from the library, tuning variables echoed, age of the counter figures
     assert rf["waves_per_simd"] == 7 and "(7 waves per SIMD)" in rf["limiter"]
@@ -229,6 +229,6 @@ def test_bench_refuses_tuning_overrides_when_strict():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["config"]["env_overrides"] == {"BM_REFILL_MIN": 8, "BM_HELPERS": 0}
-    assert out["config"]["frame_plan"]["helpers"] == 0 and out["config"]["frame_plan"]["refill_min"] == 8 and "false, false" in out["roofline"]["kernel"]
+    assert out["config"]["frame_plan"]["helpers"] == 0 and out["config"]["frame_plan"]["refill_min"] == 8 and "<false, false, false, 0>" in out["roofline"]["kernel"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, BM_BENCH_STRICT="1"), cwd=ROOT)
     assert r.returncode != 0 and "tuning overrides" in (r.stdout + r.stderr) and not [l for l in r.stdout.splitlines() if l.startswith("{")]
