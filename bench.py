@@ -289,6 +289,7 @@ def main():
     # 20, 0.765 after 60).  Untimed frames of the workload's own shape into a scratch buffer, for --spinup-ms of wall time, before the W
     # warm-up steps: what is timed is the kernel, not the governor.  (Nothing here touches the timed region or its buffers.)
     spun_ms = 0.0
+    launch_frames_log = []  # frames of every trace_paths launch of this process up to the end of the timed region, in order (resident workloads)
     if args.spinup_ms > 0 and not streaming:
         spin_buf = torch.zeros_like(accum)
         t_spin = time.perf_counter()
@@ -302,6 +303,7 @@ def main():
                 scene.render(cam, ps[0], spin_buf)
             torch.cuda.synchronize()
             k += n_spin
+            launch_frames_log.append(n_spin)
         spun_ms = (time.perf_counter() - t_spin) * 1e3
         del spin_buf
 
@@ -328,6 +330,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
     launch_ms = scene.render_times(len(timed))  # HIP events on the launch stream, one pair per launch
+    launch_frames_log += [c for _, c in batches(0, args.warmup, per_launch)] + [c for _, c in timed]
+    launch_ms_log = scene.render_times(len(launch_frames_log)) if (not streaming and len(launch_frames_log) <= 256) else None
     kernel_ms_per_step = float(np.sum(launch_ms)) / args.steps
     ranks_info = None
     if multi:
@@ -583,6 +587,10 @@ def main():
             "launches": len(timed), "frames_per_launch": [c for _, c in timed],
             "kernel_ms_avg": round(float(np.mean(launch_ms)), 4),   # average duration of one timed LAUNCH of `kernel` (what rocprofv3 --stats reports for it)
             "kernel_ms_per_step": round(kernel_ms_per_step, 4),
+            # every launch of `kernel` this process made up to the end of the timed region (spin-up, warm-up, timed), so that the
+            # per-kernel average of `rocprofv3 --stats` over a --no-extras run can be re-derived: it averages launches of different frame
+            # counts; sum(frames) x algorithmic_bytes_per_step / sum(ms) is the rate over all of them, the last `launches` entries are the timed ones
+            "launch_log": ({"frames": launch_frames_log, "ms": [round(float(t), 4) for t in launch_ms_log]} if launch_ms_log is not None else None),
             "algorithmic_bytes_per_launch": alg_bytes / len(timed),
             "algorithmic_bytes_per_step": bytes_per_step,
             "bytes_per_actual_ray": round(alg_bytes / max(actual_rays, 1), 1),
