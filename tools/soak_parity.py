@@ -1,7 +1,8 @@
 """Randomised parity soak (GPU box): many seeded views / suns / lenses / sample offsets / LoD thresholds on two worlds
 (256^3 and the non-cubic 384 x 384 x 128), the HIP path against the oracle: hit records bit-exact, radiance within 1e-4,
 and the production instantiation bit-identical to the instrumented one; the production default (helper lanes, float atomics)
-equal up to summation order.  usage: python tools/soak_parity.py [trials=400] [seed=1]"""
+equal up to summation order; the helper-lane frame's ray digest (BM_FLAG_RAY_DIGEST) equal to the oracle's; the first frame of a
+uniform frame-ring launch equal to the ordered frame.  usage: python tools/soak_parity.py [trials=400] [seed=1]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -42,6 +43,12 @@ for t in range(trials):
     scene.render(cam, p_ord, plain)                    # production instantiation, ordered sums: the instrumented frame's bits
     prod = torch.zeros_like(acc)
     scene.render(cam, p, prod)                         # production default: helper lanes, (chunk, sample) items for spp >= 2, float atomics
+    dig = torch.zeros_like(dbg)
+    pd = bm.FrameParams(W, H, spp=spp, sample_base=sb, max_bounces=mb, sun_position=sun, flags=bm.BM_FLAG_RAY_DIGEST)
+    scene.render(cam, pd, torch.zeros_like(acc), debug=dig)   # the helper-lane instantiation's own hit records: the order-independent ray digest
+    ring = torch.zeros((3,) + tuple(acc.shape), dtype=torch.float32, device="cuda:0")
+    pr = [bm.FrameParams(W, H, spp=spp, sample_base=sb + k * spp, max_bounces=mb, sun_position=sun, flags=bm.BM_FLAG_ORDERED) for k in range(3)]
+    scene.render_frames(cam, pr, [ring[k] for k in range(3)])  # a uniform frame-ring launch: its first frame is the ordered frame, bit for bit
     torch.cuda.synchronize()
     oacc, odbg, _, _ = world.render(ocam, orc.make_frame(W, H, spp=spp, max_bounces=mb, sample_base=sb, sun=sun), threads=os.cpu_count() or 1)
     a, b, d = acc.cpu().numpy(), plain.cpu().numpy(), dbg.cpu().numpy().view(np.uint32)
@@ -50,6 +57,7 @@ for t in range(trials):
     both = np.isfinite(a) & np.isfinite(c)
     ok = ok and np.array_equal(np.isfinite(a), np.isfinite(c)) and np.array_equal(np.where(both, c, 0)[..., 3], np.where(both, a, 0)[..., 3]) \
         and np.allclose(np.where(both, c, 0)[..., :3], np.where(both, a, 0)[..., :3], rtol=2e-5, atol=1e-7)
+    ok = ok and np.array_equal(dig.cpu().numpy().view(np.uint32), world.last_ray_digest) and np.array_equal(ring[0].cpu().numpy().view(np.uint32), a.view(np.uint32))
     fin = np.isfinite(oacc)
     ok = ok and np.array_equal(np.isfinite(a), fin)
     err = float((np.abs(np.where(fin, a, 0) - np.where(fin, oacc, 0)) / np.maximum(np.abs(np.where(fin, oacc, 0)), 1e-6)).max())
