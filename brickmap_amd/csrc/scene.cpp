@@ -1100,7 +1100,6 @@ int Scene::render_frames(int count, const bm_camera* cams, const bm_frame_params
 	if (int e = frame_end(stream)) return e; // what process_load_queue orders itself behind
 	for (int e = first; e < first + count; ++e) ring_owner_[e] = launches_;
 	ring_next_ = first + count;
-	launch_frames_[slot] = count;
 	launches_++;
 	return 0;
 }

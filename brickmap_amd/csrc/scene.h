@@ -130,7 +130,6 @@ private:
 	uint32_t* d_work_counter_ = nullptr; // chunk counters of the persistent trace kernel: kFrameRing blocks of kWorkCounterBytes, zeroed before the launch that uses them
 	long long ring_owner_[kFrameRing];   // the launch (value of launches_) that used the entry last, -1 = none
 	int ring_next_ = 0;
-	int launch_frames_[kTimingRing] = {}; // frames of the launch in each timing slot
 	int compute_units_ = 0, blocks_per_cu_[2] = {0, 0};
 	// pinned staging (Scene.cpp:30-32)
 	int* h_positions_[2] = {nullptr, nullptr};
