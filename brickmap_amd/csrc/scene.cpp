@@ -1013,6 +1013,7 @@ int Scene::render_frames(int count, const bm_camera* cams, const bm_frame_params
 		}
 	}
 	const FrameConstants& fc = fcs[0];
+	bool shared_digest = false; // ray-digest frames that all write ONE hit-record buffer (and one accumulation buffer)
 	if (count > 1) {
 		// Frames of a launch overlap in time.  Hit records are written with plain stores, and so are the pixels of frames that neither
 		// run helper lanes nor (chunk, sample) items (read when a lane takes the pixel, written back when it is done): such frames
@@ -1028,6 +1029,7 @@ int Scene::render_frames(int count, const bm_camera* cams, const bm_frame_params
 					return BM_EINVAL;
 				}
 				const char *c = dbgs ? reinterpret_cast<const char*>(dbgs[i]) : nullptr, *d = dbgs ? reinterpret_cast<const char*>(dbgs[k]) : nullptr;
+				if (c && d && c == d && a == b && (fc.flags & BM_FLAG_RAY_DIGEST)) { shared_digest = true; continue; } // (allowed for uniform launches: below)
 				if (c && d && c < d + pixels * 32 && d < c + pixels * 32) {
 					set_error("bm_render_frames: the frames of one launch need hit-record buffers of their own");
 					return BM_EINVAL;
@@ -1037,7 +1039,12 @@ int Scene::render_frames(int count, const bm_camera* cams, const bm_frame_params
 	// ---- a UNIFORM launch?  Frames that differ only in sample_base and buffers, both stepping by constants (a resting camera: the
 	// reference's progressive accumulation; bench.py's steps; a rank's batch into one allocation): lanes of consecutive frames may then
 	// share a wave (trace.hip), because nothing a lane reads after it took its item depends on the frame any more.
-	if (count > 1 && !hit_records) {
+	bool digest_ok = false;
+	if (shared_digest) { // every frame names the same two buffers?
+		digest_ok = true;
+		for (int i = 0; i < count; ++i) digest_ok = digest_ok && dbgs[i] == dbgs[0] && accums[i] == accums[0];
+	}
+	if (count > 1 && (!hit_records || digest_ok)) {
 		auto same_view = [&](const FrameConstants& a, const FrameConstants& b) {
 			// everything up to `width` is the view, the sun and the sky (device_types.h); base_frame seeds the RNG
 			return std::memcmp(&a, &b, offsetof(FrameConstants, width)) == 0 && a.base_frame == b.base_frame;
@@ -1060,6 +1067,13 @@ int Scene::render_frames(int count, const bm_camera* cams, const bm_frame_params
 			fcs[0].ring_sample_stride = static_cast<int>(sample_stride);
 			fcs[0].ring_pixel_stride = static_cast<uint32_t>(byte_stride / 16);
 		}
+		if (shared_digest && !uniform) digest_ok = false;
+	}
+	if (shared_digest && !digest_ok) {
+		// One hit-record buffer for several frames is the digest of the WHOLE launch: its keys count samples from the first frame's
+		// sample_base and its first-hit record is written once -- which only a uniform launch (one view, stepping sample_base) defines
+		set_error("bm_render_frames: ray-digest frames may share one hit-record buffer only in a uniform launch (one view and sun, sample_base stepping by a constant, one accumulation buffer)");
+		return BM_EINVAL;
 	}
 	BM_HIP(hipSetDevice(device_));
 	// `stream` is used as given: nullptr is HIP's default stream (what the reference's <<<>>> launches use), which is

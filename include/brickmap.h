@@ -235,7 +235,10 @@ BM_API int bm_render_frame(bm_scene* scene, const bm_camera* camera, const bm_fr
  * same (BM_EINVAL otherwise).  Frames of a launch OVERLAP in time: ordered frames (BM_FLAG_ORDERED, hit records, primary-only)
  * write pixels back with plain stores and need accumulation buffers of their own; production frames add with float atomics
  * and may share one buffer, like consecutive frames of the reference's accumulation.  debug_dev: NULL, or `count` entries, each
- * NULL or a hit-record buffer of its own.  Results of ordered frames are bit-identical to `count` single launches.  Bricks
+ * NULL or a hit-record buffer of its own (BM_FLAG_RAY_DIGEST frames of one view whose sample_base steps by a constant and that share
+ * their accumulation buffer may also share ONE hit-record buffer: it then holds the digest of the whole launch, samples counted from
+ * the first frame's sample_base -- for sample_base stepping by spp, the digest of one frame of count x spp samples).  Results of ordered
+ * frames are bit-identical to `count` single launches.  Bricks
  * requested by any frame of the launch are serviced by the next bm_scene_process_load_queue.  bm_render_times /
  * bm_last_render_ms report the launch as one duration. */
 BM_API int bm_render_frames(bm_scene* scene, int count, const bm_camera* cameras, const bm_frame_params* params,

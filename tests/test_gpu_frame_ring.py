@@ -126,6 +126,26 @@ def test_uniform_launch_mixes_frames_inside_a_wave(bm, orc, torch_cuda, scene256
     oacc, _, _, _ = world256.render(ocam, orc.make_frame(W, H, spp=K, max_bounces=3), want_dbg=False)
     assert np.all(ring[..., 3].cpu().numpy() == K)
     assert_radiance(ring.cpu().numpy(), oacc)
+    # ... on HITS, bit for bit, and on the traversal counters: the instrumented sibling of the kernel bench.py times
+    # (trace_paths<true, *, true, 2>: helper lanes, lanes of several frames in one wave) writes the ray digest of the whole launch into one
+    # buffer -- the oracle's digest of the K-sample frame -- and counts the oracle's cells, brick tests and rays
+    for spp in (1, 2):
+        acc = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+        dig = torch.zeros((H, W, 8), dtype=torch.int32, device="cuda:0")
+        ps = [bm.FrameParams(W, H, spp=spp, sample_base=5 + spp * k, max_bounces=3, flags=bm.BM_FLAG_RAY_DIGEST | bm.BM_FLAG_COUNTERS) for k in range(K)]
+        scene256.counters_reset()
+        scene256.render_frames(cam, ps, acc, debugs=[dig] * K)
+        torch.cuda.synchronize()
+        got_cnt = scene256.counters()
+        scene256.counters_reset()
+        world256.reset_device(True)
+        oacc, _, ocnt, _ = world256.render(ocam, orc.make_frame(W, H, spp=K * spp, sample_base=5, max_bounces=3))
+        assert np.array_equal(dig.cpu().numpy().view(np.uint32), world256.last_ray_digest), "uniform launch: ray digest differs from the oracle's"
+        assert got_cnt == ocnt
+        assert_radiance(acc.cpu().numpy(), oacc)
+    # one hit-record buffer for frames of DIFFERENT views is refused (its keys and its first-hit record would not be defined)
+    with pytest.raises(bm.BrickmapError, match="uniform launch"):
+        scene256.render_frames([cam, fly(bm, orc, 3)[0]], ps[:2], acc, debugs=[dig, dig])
 
 
 def test_counters_of_a_launch_are_the_sum_of_its_frames(bm, orc, torch_cuda, scene256, world256):

@@ -578,6 +578,18 @@ def test_full_size_config2_properties(bm, orc, torch_cuda):
     # production-plan render (the first gpu_render call above) on the same 18 rows
     assert np.array_equal(digest_full[rows], w.last_ray_digest[rows]), "config 2 at full size: the helper-lane frame's ray digest differs from the oracle's"
     assert int((digest_full[..., 6] & 0xFFFF).sum()) == cnt["extend_rays"] and int(digest_full[..., 7].astype(np.uint64).sum()) == cnt["index_loads"]
+    # ... and as bench.py ISSUES its steps: consecutive frames of one view as ONE uniform frame-ring launch (trace_paths<*, false, true, 2>,
+    # lanes of several frames in one wave), here three frames with the ray digest of the whole launch in one buffer = the oracle's digest
+    # of the 3-sample frame, on the same 18 rows
+    acc3 = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    dig3 = torch.zeros((H, W, 8), dtype=torch.int32, device="cuda:0")
+    scene.render_frames(cam, [bm.FrameParams(W, H, spp=1, sample_base=k, max_bounces=3, flags=bm.BM_FLAG_RAY_DIGEST) for k in range(3)], acc3, debugs=[dig3] * 3)
+    torch.cuda.synchronize()
+    oacc3, _, _, _ = w.render(ocam, orc.make_frame(W, H, spp=3, max_bounces=3, band_rows=1, shard_rank=7, shard_count=60), threads=os.cpu_count() or 1)
+    assert np.array_equal(dig3.cpu().numpy().view(np.uint32)[rows], w.last_ray_digest[rows]), "config 2 at full size, frame ring: ray digest differs from the oracle's"
+    a3 = acc3.cpu().numpy()
+    assert np.all(a3[..., 3] == 3.0)
+    assert_radiance(a3[rows], oacc3[rows])
     scene.close()
 
 

@@ -49,6 +49,10 @@ for t in range(trials):
     ring = torch.zeros((3,) + tuple(acc.shape), dtype=torch.float32, device="cuda:0")
     pr = [bm.FrameParams(W, H, spp=spp, sample_base=sb + k * spp, max_bounces=mb, sun_position=sun, flags=bm.BM_FLAG_ORDERED) for k in range(3)]
     scene.render_frames(cam, pr, [ring[k] for k in range(3)])  # a uniform frame-ring launch: its first frame is the ordered frame, bit for bit
+    rdig, racc = torch.zeros_like(dbg), torch.zeros_like(acc)
+    if spp * 3 * (mb + 1) < 65536:
+        pg = [bm.FrameParams(W, H, spp=spp, sample_base=sb + k * spp, max_bounces=mb, sun_position=sun, flags=bm.BM_FLAG_RAY_DIGEST) for k in range(3)]
+        scene.render_frames(cam, pg, racc, debugs=[rdig] * 3)  # production frames of a uniform launch, ONE digest buffer: the oracle's digest of the 3 x spp frame
     torch.cuda.synchronize()
     oacc, odbg, _, _ = world.render(ocam, orc.make_frame(W, H, spp=spp, max_bounces=mb, sample_base=sb, sun=sun), threads=os.cpu_count() or 1)
     a, b, d = acc.cpu().numpy(), plain.cpu().numpy(), dbg.cpu().numpy().view(np.uint32)
@@ -58,6 +62,8 @@ for t in range(trials):
     ok = ok and np.array_equal(np.isfinite(a), np.isfinite(c)) and np.array_equal(np.where(both, c, 0)[..., 3], np.where(both, a, 0)[..., 3]) \
         and np.allclose(np.where(both, c, 0)[..., :3], np.where(both, a, 0)[..., :3], rtol=2e-5, atol=1e-7)
     ok = ok and np.array_equal(dig.cpu().numpy().view(np.uint32), world.last_ray_digest) and np.array_equal(ring[0].cpu().numpy().view(np.uint32), a.view(np.uint32))
+    world.render(ocam, orc.make_frame(W, H, spp=3 * spp, max_bounces=mb, sample_base=sb, sun=sun), threads=os.cpu_count() or 1)
+    ok = ok and np.array_equal(rdig.cpu().numpy().view(np.uint32), world.last_ray_digest)
     fin = np.isfinite(oacc)
     ok = ok and np.array_equal(np.isfinite(a), fin)
     err = float((np.abs(np.where(fin, a, 0) - np.where(fin, oacc, 0)) / np.maximum(np.abs(np.where(fin, oacc, 0)), 1e-6)).max())
