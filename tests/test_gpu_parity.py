@@ -1273,7 +1273,7 @@ def test_bench_starts_its_own_ranks(bm, torch_cuda, tmp_path):
 
 
 def test_frames_overlapping_on_two_streams(bm, orc, torch_cuda, scene256):
-    """Consecutive frames issued on two streams (what bench.py --pipeline 2 does) may run at the same time: every launch has its
+    """Consecutive frames issued on two streams (what a host that pipelines frames over streams does) may run at the same time: every launch has its
     own ticket counters and constants, and with BM_FLAG_SAMPLE_ITEMS samples are added atomically, so the buffer ends up
     with the same paths as the frames rendered one after the other."""
     torch = torch_cuda
