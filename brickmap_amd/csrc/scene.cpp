@@ -1075,6 +1075,16 @@ int Scene::render_frames(int count, const bm_camera* cams, const bm_frame_params
 		set_error("bm_render_frames: ray-digest frames may share one hit-record buffer only in a uniform launch (one view and sun, sample_base stepping by a constant, one accumulation buffer)");
 		return BM_EINVAL;
 	}
+	{ // the kernel's hang guard is a 64-bit product (trace.hip round_budget): a launch for which it would wrap -- it would end before it has
+	  // traced anything -- is refused (such a launch is weeks of GPU time anyway)
+		const unsigned __int128 rounds = static_cast<unsigned __int128>(static_cast<unsigned long long>(fc.tiles_x) * static_cast<unsigned long long>(fc.tiles_y) * 16ull + 64ull) *
+										 static_cast<unsigned long long>(fc.spp + 1) * static_cast<unsigned long long>(fc.max_bounces + 2) *
+										 static_cast<unsigned long long>(2ll * world.dims.cells + world.dims.cells_height + 64) * static_cast<unsigned long long>(count);
+		if (rounds >= (static_cast<unsigned __int128>(1) << 62)) {
+			set_error("launch too large: tiles x samples x segments x frames overflows the kernel's round budget (render fewer samples or frames per launch)");
+			return BM_EINVAL;
+		}
+	}
 	BM_HIP(hipSetDevice(device_));
 	// `stream` is used as given: nullptr is HIP's default stream (what the reference's <<<>>> launches use), which is
 	// ordered with the caller's other default-stream work (e.g. torch's fill kernels on the accumulation buffer).
