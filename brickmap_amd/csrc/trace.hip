@@ -291,9 +291,7 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			++ring_pos;
 			accum = reinterpret_cast<float4*>(fc.accum);
 			if (DBG) dbg = fc.dbg;
-			my_counter = first_counter();
-			counters_done = 0;
-			work_left = 1;
+			work_left = 1; // (same ticket counter, next frame)
 		}
 		if (work_left == 1 && nI >= fg.refill_min) {
 			// One global word serves only ~90 returning atomics per microsecond chip-wide, and a refill stalls the whole
@@ -313,7 +311,16 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 			const uint32_t my_tickets = my_units * (xcd_handout ? kStChunks : 4u) * items_per_chunk; // consecutive tickets = the samples of one chunk
 			const uint32_t counter_now = static_cast<uint32_t>(my_counter);
 			const int ring_at_refill = kRing ? ring_pos : 0;
-			if (base + want >= my_tickets) { // this counter is used up: move to the next one (helping out), or finish
+			if (kRing && !XCD && base + want >= my_tickets && more_frames()) {
+				// this counter of the wave's frame is used up and the launch has more frames: on to the SAME counter of the next frame --
+				// at once in a uniform launch (see below), once every lane is idle otherwise.  (Going round the frame's other counters
+				// first, as a launch's last frame does, is sixteen refills that hand out nothing, per wave and frame -- 1.5 % of a
+				// 1080p frame; whatever the other counters still hold is traced by the waves that are on them.  Not with the XCD-aware
+				// hand-out, whose counters own whole super-tiles and may differ by one: there the waves of a light counter would run
+				// frames ahead of the others and could only help them on the launch's last frame.)
+				if (kUniform) ++ring_pos;
+				else work_left = 2;
+			} else if (base + want >= my_tickets) { // this counter is used up: move to the next one (helping out), or finish
 				my_counter = (my_counter + 1) % static_cast<int>(kCounters);
 				if (++counters_done >= static_cast<int>(kCounters)) {
 					// the frame's tickets are gone.  UNIFORM launches (FrameConstants::ring_uniform: the frames share view, sun and base_frame;
@@ -321,11 +328,13 @@ __global__ __launch_bounds__(256, DBG ? 2 : BM_WAVES_PER_SIMD) void trace_paths(
 					// main.cpp:117-147 with no input) go straight on: a lane's frame is folded into its sample index and its pixel offset
 					// when it takes its item (below), every other constant is the same in all frames, so lanes of two frames share
 					// the wave and the wave never runs empty between frames -- only at the end of the launch.
-					if (kRing && more_frames()) {
-						if (kUniform) { ++ring_pos; my_counter = first_counter(); counters_done = 0; }
+					if (kRing && more_frames()) { // (XCD-aware hand-out: the whole frame is handed out, the next one starts on the wave's own counter)
+						counters_done = 0;
+						my_counter = first_counter();
+						if (kUniform) ++ring_pos;
 						else work_left = 2;
 					} else {
-						work_left = 0;
+						work_left = 0; // (the launch's last frame: nothing left anywhere)
 						if (BM_TIMED) t_dry = __builtin_amdgcn_s_memtime();
 					}
 				}
