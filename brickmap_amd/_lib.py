@@ -41,7 +41,7 @@ class bm_frame_params(C.Structure):
 
 class bm_frame_plan(C.Structure):
     _fields_ = [("flags", C.c_uint32), ("ordered", C.c_int32), ("helpers", C.c_int32), ("sample_items", C.c_int32), ("xcd_handout", C.c_int32),
-                ("refill_min", C.c_int32), ("instrumented", C.c_int32), ("tiles_x", C.c_int32), ("tiles_y", C.c_int32), ("local_rows", C.c_int32)]
+                ("refill_min", C.c_int32), ("refill_min_in_ring", C.c_int32), ("instrumented", C.c_int32), ("tiles_x", C.c_int32), ("tiles_y", C.c_int32), ("local_rows", C.c_int32)]
 
 
 class bm_scene_info(C.Structure):

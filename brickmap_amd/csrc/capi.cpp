@@ -212,6 +212,7 @@ int bm_frame_plan_of(const bm_frame_params* params, int hit_records, bm_frame_pl
 	out->ordered = (fc.helpers || out->sample_items) ? 0 : 1;
 	out->xcd_handout = fc.xcd_handout;
 	out->refill_min = fc.refill_min;
+	out->refill_min_in_ring = bm::ring_refill_min(fc.refill_min, fc.helpers != 0, bm::tuning().refill_min);
 	out->tiles_x = fc.tiles_x; out->tiles_y = fc.tiles_y; out->local_rows = fc.local_rows;
 	out->instrumented = (hit_records || (fc.flags & BM_FLAG_COUNTERS)) ? 1 : 0;
 	return 0;

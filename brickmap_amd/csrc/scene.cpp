@@ -1015,8 +1015,8 @@ int Scene::render_frames(int count, const bm_camera* cams, const bm_frame_params
 	// In a launch of several frames a wave refills later: what argues for an early refill in a lone frame -- the paths started last are what
 	// the frame's end waits for -- does not count when the next frame covers that end (ring of 20, kernel ms per frame: 24 idle lanes 0.7514,
 	// 32: 0.7478, 36: 0.7481, 40: 0.7515; 1080p at 4 spp 2.937 / 2.905 / 2.894 / 2.899; profiles/r06_frame_ring.txt)
-	if (count > 1 && fcs[0].helpers && !(tuning().refill_min >= 1 && tuning().refill_min <= 64))
-		for (FrameConstants& f : fcs) f.refill_min = 32;
+	if (count > 1)
+		for (FrameConstants& f : fcs) f.refill_min = ring_refill_min(f.refill_min, f.helpers != 0, tuning().refill_min);
 	const FrameConstants& fc = fcs[0];
 	bool shared_digest = false; // ray-digest frames that all write ONE hit-record buffer (and one accumulation buffer)
 	if (count > 1) {

@@ -26,6 +26,12 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 void division_magic(uint32_t d, uint32_t* magic, int* shift); // floor(n / d) = umulhi(n, magic) >> shift for n < 2^30 (scene.cpp)
 
+// a wave of a multi-frame launch (the frame ring) with helper lanes takes new items once this many of its lanes are idle (scene.cpp render_frames)
+constexpr int kRingRefillMin = 32;
+inline int ring_refill_min(int single_frame_refill_min, bool helpers, int override_refill_min) {
+	return (helpers && !(override_refill_min >= 1 && override_refill_min <= 64)) ? kRingRefillMin : single_frame_refill_min;
+}
+
 // tuning overrides from the environment (scene.cpp tuning()): 0 / -1 = not set
 struct Tuning {
 	int refill_min = 0, xcd_handout = -1, helpers = -1, blocks_per_cu = 0;

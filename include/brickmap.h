@@ -254,6 +254,7 @@ typedef struct bm_frame_plan {
 	int32_t sample_items;  /* 1: (4x4 chunk, sample) work items                                                                  */
 	int32_t xcd_handout;   /* 1: 256x256-pixel super-tiles dealt to the eight XCDs' ticket counters (big frames)                 */
 	int32_t refill_min;    /* a wave takes new work items once this many of its lanes are idle                                    */
+	int32_t refill_min_in_ring; /* ... when the frame is one of several of a bm_render_frames launch (later: its end is covered)     */
 	int32_t instrumented;  /* 1: the instrumented instantiation (hit records / BM_FLAG_COUNTERS) runs                             */
 	int32_t tiles_x, tiles_y, local_rows;
 } bm_frame_plan;

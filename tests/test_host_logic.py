@@ -172,6 +172,7 @@ def test_frame_plan_and_ticket_limits():
     import brickmap_amd as bm
     p1 = bm.frame_plan(bm.FrameParams(1920, 1080, spp=1, max_bounces=3))
     assert (p1["helpers"], p1["sample_items"], p1["ordered"], p1["xcd_handout"], p1["refill_min"], p1["instrumented"]) == (1, 0, 0, 0, 24, 0)
+    assert p1["refill_min_in_ring"] == 32 and bm.frame_plan(bm.FrameParams(64, 64, spp=2, flags=bm.BM_FLAG_ORDERED))["refill_min_in_ring"] == 8  # (ordered: as a lone frame)
     p4 = bm.frame_plan(bm.FrameParams(1920, 1080, spp=4, max_bounces=3))
     assert p4["sample_items"] == 1 and p4["flags"] & bm.BM_FLAG_SAMPLE_ITEMS
     for W, H, spp in ((1920, 1080, 5000), (3840, 2160, 1000), (7680, 4320, 300)):  # (beyond the limits the advisor computed: 4100 / 950 / 250)
